@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: grasp candidates scored per second at P=750 on N MI355X.
+
+One "step" = one full eval forward of PointNetCls(750,3,2) (STN stack, STN regressor, trunk
+stack, classifier head, log-softmax) over a batch of 4096 synthetic candidates per GPU that are
+already resident in HBM.  Candidates are sharded data-parallel: every rank scores its own 4096
+(weak scaling), no collective is on the data path.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (the fused bf16 conv stack)
+from a live HIP-event measurement; `cpu_baseline` times the CPU oracle (the reference's op
+sequence in eager PyTorch) on the host cores of the same box.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pointnetgpd_amd import _lib, synth  # noqa: E402
+from pointnetgpd_amd.pointnet import PointNetCls  # noqa: E402
+
+# algorithmic work, BN folded, 1 MAC = 2 flop (bias / ReLU / max / softmax not counted)
+FLOP_PER_POINT_STACK = 2 * (3 * 64 + 64 * 128 + 128 * 1024)          # 278,912
+FLOP_FC_STN = 2 * (1024 * 512 + 512 * 256 + 256 * 9)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}                        # dense MFMA peaks, MI355X
+
+
+def flop_per_candidate(P, k):
+    return P * (2 * FLOP_PER_POINT_STACK + 18) + FLOP_FC_STN + 2 * (1024 * 512 + 512 * 256 + 256 * k)
+
+
+def device_points(seed, B, P, rank, device):
+    """Candidate points generated on the device: uniform in the synthetic gripper box, keyed by
+    (seed, global candidate id) so that the data of a candidate does not depend on the sharding."""
+    g = torch.Generator(device=device)
+    out = torch.empty((B, 3, P), dtype=torch.float32, device=device)
+    hd, ow, hh = synth.GRIPPER_BOX
+    scale = torch.tensor([hd, ow, hh], device=device).view(1, 3, 1)
+    shift = torch.tensor([0.0, -ow / 2, -hh / 2], device=device).view(1, 3, 1)
+    chunk = 1024
+    for c0 in range(0, B, chunk):
+        g.manual_seed(seed * 1_000_003 + (rank * B + c0))
+        n = min(chunk, B - c0)
+        out[c0:c0 + n] = torch.rand((n, 3, P), generator=g, device=device) * scale + shift
+    return out
+
+
+def cpu_baseline(P, k, seed, seconds_budget=15.0):
+    """Oracle (eager fp32 PyTorch on the host CPU), B=64 batches - the reference's batched eval shape."""
+    from oracle import pointnet_oracle as po
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    m = po.build_cls(P, k, synth.torch_state_dict(seed, k, 0.02))
+    x = torch.from_numpy(synth.candidate_points(seed, 64, P, "gripper"))
+    with torch.no_grad():
+        m(x)
+        t0 = time.perf_counter()
+        m(x)
+        one = time.perf_counter() - t0
+        iters = int(max(3, min(40, seconds_budget / max(one, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            m(x)
+        dt = time.perf_counter() - t0
+    return {"value": round(64 * iters / dt, 2), "unit": "candidates/s", "cores": threads, "kind": "port",
+            "sample": f"oracle PointNetCls({P},3,{k}).eval() fp32, {iters} batches of 64 candidates, "
+                      f"torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4096, help="candidates per GPU")
+    ap.add_argument("--points", type=int, default=750)
+    ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    n_gpus = world
+    if n_gpus != args.gpus and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    B, P, k, seed = args.batch, args.points, args.classes, 0
+    model = PointNetCls(P, 3, k)
+    model.load_state_dict(synth.torch_state_dict(seed, k, 0.02), strict=True)
+    model = model.to(dev).eval()
+    model.precision = args.precision
+    x = device_points(seed, B, P, rank, dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        model(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logp, trans = model(x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(logp).all()
+
+    # dominant kernel: fused conv stack, timed alone with HIP events on the launch stream
+    h = model._handle(dev)
+    ws = h.workspace(B)
+    ms = ctypes.c_float(0.0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    prec = _lib.PRECISIONS[args.precision]
+    _lib.check(h.lib.pngpd_profile_conv_stack(h.ptr, ctypes.c_void_p(x.data_ptr()), _lib.LAYOUT_C3P, B, P, prec, 1,
+                                              20, ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.byref(ms),
+                                              ctypes.c_void_p(stream)))
+    flop_launch = float(B) * P * FLOP_PER_POINT_STACK
+    achieved = flop_launch / (ms.value * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.precision]
+
+    if rank == 0:
+        total = float(n_gpus) * B * args.steps
+        line = {
+            "metric": "grasp candidates scored/sec at N=750",
+            "value": round(total / elapsed, 1),
+            "unit": "candidates/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": f"PointNetCls {k}-class eval forward, P={P}, batch {B} per GPU, "
+                                   f"{args.precision} fused conv/max-pool kernels + fp32 FC, synthetic weights",
+                       "batch_per_gpu": B, "points": P, "classes": k, "parallelism": f"dp{n_gpus}",
+                       "whole_net_tflops": round(total / elapsed * flop_per_candidate(P, k) / 1e12, 2)},
+            "roofline": {"bound": "mfma", "kernel": f"conv_stack_{args.precision}", "achieved": round(achieved, 2),
+                         "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                         "kernel_ms": round(ms.value, 4), "flop_per_launch": flop_launch},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(P, k, seed)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+/*
+ * pngpd.h - C ABI of the MI355X (gfx950) grasp-scoring library.
+ *
+ * The reference (Hymwgk/PointNetGPD) has no FFI of its own: the hot path sits behind three
+ * PyTorch modules (model/pointnet.py) and a numpy crop loop (apps/kinect2grasp.py).  This header
+ * is what a binding for that path calls instead; every entry point cites the reference code whose
+ * arithmetic it replaces.
+ *
+ * Conventions
+ *  - Every pointer named *_dev is caller-owned DEVICE memory on the device that was current when
+ *    the model was created.  The library never frees or keeps caller buffers.
+ *  - `stream` is a hipStream_t passed as void*; all work is stream-ordered on it, nothing
+ *    synchronises the host unless stated.
+ *  - Return value: PNGPD_OK (0) or an error code; pngpd_last_error() gives the message of the
+ *    last failure on the calling thread.  No C++ exception crosses this boundary.
+ *  - Shapes follow the reference: P points per candidate must equal the model's num_points
+ *    (model/pointnet.py:15,132 MaxPool1d(num_points) fails otherwise) and input_chann is 3
+ *    (model/pointnet.py:139, 3x3 bmm).
+ */
+#ifndef PNGPD_H
+#define PNGPD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    PNGPD_OK = 0,
+    PNGPD_ERR_INVALID = 1,   /* null pointer / bad enum / bad size                  */
+    PNGPD_ERR_SHAPE = 2,     /* P != num_points, B < 1, k out of range ...           */
+    PNGPD_ERR_HIP = 3,       /* a HIP runtime call failed (message has the reason)   */
+    PNGPD_ERR_STATE = 4,     /* weights not loaded, model part missing               */
+    PNGPD_ERR_WORKSPACE = 5  /* workspace smaller than pngpd_*_workspace_bytes()     */
+};
+
+/* arithmetic of the two fused conv stacks (FC layers are always fp32) */
+enum { PNGPD_FP32 = 0, PNGPD_BF16 = 1 };
+
+/* memory layout of the candidate points */
+enum {
+    PNGPD_LAYOUT_C3P = 0, /* [B,3,P]  what the reference modules take (model/pointnet.py:185) */
+    PNGPD_LAYOUT_P3 = 1   /* [B,P,3]  what the crop emits (apps/kinect2grasp.py:423,768)       */
+};
+
+/* which sub-networks a model owns */
+enum {
+    PNGPD_PART_STN = 1,   /* STN3d        model/pointnet.py:8-45     */
+    PNGPD_PART_TRUNK = 2, /* PointNetfeat model/pointnet.py:122-152  */
+    PNGPD_PART_HEAD = 4   /* PointNetCls  model/pointnet.py:174-190  */
+};
+
+/*
+ * Weight table passed to pngpd_model_load(): 12 layer units x 6 fields, host float32 pointers.
+ * slot = unit * PNGPD_FIELDS + field.  Units without BatchNorm (the two fc3) leave the four bn
+ * fields NULL.  Conv weights are [Cout,Cin,1] and linear weights [out,in], both contiguous, i.e.
+ * exactly the tensors of the reference state_dict (model/pointnet.py:12-25,126-131,179-183).
+ */
+enum {
+    PNGPD_U_STN_CONV1 = 0, PNGPD_U_STN_CONV2, PNGPD_U_STN_CONV3,
+    PNGPD_U_STN_FC1, PNGPD_U_STN_FC2, PNGPD_U_STN_FC3,
+    PNGPD_U_FEAT_CONV1, PNGPD_U_FEAT_CONV2, PNGPD_U_FEAT_CONV3,
+    PNGPD_U_FC1, PNGPD_U_FC2, PNGPD_U_FC3,
+    PNGPD_UNITS
+};
+enum {
+    PNGPD_F_WEIGHT = 0, PNGPD_F_BIAS, PNGPD_F_BN_WEIGHT, PNGPD_F_BN_BIAS, PNGPD_F_BN_MEAN,
+    PNGPD_F_BN_VAR, PNGPD_FIELDS
+};
+#define PNGPD_SLOTS (PNGPD_UNITS * PNGPD_FIELDS)
+
+typedef struct pngpd_model pngpd_model;
+
+/* Message of the last error on this thread ("" if none). */
+const char* pngpd_last_error(void);
+
+/* ABI version of this header; bumped on any incompatible change. */
+int pngpd_abi_version(void);
+
+/*
+ * Create / destroy a model for (num_points, k) on the CURRENT device.
+ * Replaces the constructors STN3d / PointNetfeat / PointNetCls (model/pointnet.py:9,123,175);
+ * `parts` is a mask of PNGPD_PART_*.
+ */
+int pngpd_model_create(pngpd_model** out, int num_points, int k, int parts);
+int pngpd_model_destroy(pngpd_model* m);
+
+/*
+ * Fold eval-mode BatchNorm (eps 1e-5, running statistics) into the preceding conv/linear layer in
+ * float64, permute into MFMA fragment order (fp32 and bf16 copies) and upload.  Replaces what
+ * load_state_dict + .eval() establish for model/pointnet.py:30-38,142-145,187-189.
+ * host_tensors: PNGPD_SLOTS host pointers (see above).  Synchronises `stream` before returning
+ * (the host staging buffers are released).
+ */
+int pngpd_model_load(pngpd_model* m, const float* const* host_tensors, int n_slots, void* stream);
+
+/* Bytes of device workspace pngpd_forward_infer() needs for a batch of B candidates. */
+size_t pngpd_forward_workspace_bytes(const pngpd_model* m, int B);
+
+/*
+ * Eval-mode forward of the loaded parts for B candidates.
+ *   PART_STN only : trans_dev                       = STN3d.forward        (model/pointnet.py:28-45)
+ *   STN|TRUNK     : feat_dev, trans_dev             = PointNetfeat.forward (model/pointnet.py:135-149)
+ *   all three     : logp_dev, trans_dev (, feat_dev)= PointNetCls.forward  (model/pointnet.py:185-190)
+ * x_dev: float32, layout PNGPD_LAYOUT_*; P must equal num_points.
+ * logp_dev [B,k] log-probabilities, trans_dev [B,3,3], feat_dev [B,1024]; any of them may be NULL
+ * when the caller does not want it.  `precision` selects PNGPD_FP32 (exact-f32 MFMA) or PNGPD_BF16.
+ */
+int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
+                        int precision, float* logp_dev, float* trans_dev, float* feat_dev,
+                        void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/*
+ * softmax over the log-probabilities and first-index arg-max, i.e. the tail of
+ * test_network() (main_test.py:80-83) for a whole batch.
+ * probs_dev [B,k] float32, pred_dev [B] int64.
+ */
+int pngpd_score(const float* logp_dev, int B, int k, float* probs_dev, int64_t* pred_dev,
+                void* stream);
+
+/*
+ * Diagnostic: time the fused conv-stack kernel alone.  Launches the STN stack (which = 0) or the
+ * trunk stack (which = 1; uses an identity transform) `iters` times on `stream` between two HIP
+ * events recorded on that stream, waits for the second event and returns the mean kernel time in
+ * milliseconds.  Used by bench.py for the roofline figure; no counterpart in the reference.
+ */
+int pngpd_profile_conv_stack(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
+                             int precision, int which, int iters, void* workspace_dev,
+                             size_t workspace_bytes, float* mean_ms_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNGPD_H */

@@ -77,6 +77,8 @@ def build_probe(force: bool = False) -> str:
 def build_oracle_c(force: bool = False) -> str:
     """Compile the plain-C crop restatement used only by tests/bench as the checker."""
     src = os.path.join(ROOT, "oracle", "crop_oracle.c")
+    if not os.path.exists(src):
+        return ""
     os.makedirs(os.path.dirname(ORACLE_C_PATH), exist_ok=True)
     if force or _newer(ORACLE_C_PATH, [src]):
         _run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", src, "-o", ORACLE_C_PATH, "-lm"])

@@ -1,0 +1,312 @@
+// C-ABI layer: argument checking, weight upload, kernel sequencing.  No kernel code here.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "pack.h"
+#include "pngpd.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(PNGPD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t upload(const void* src, size_t bytes, hipStream_t s) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, s);
+    }
+};
+
+struct StackDev {
+    DevBuf w1tab, b2p, b3, w2_bf16, w3_bf16, w2_f32, w3_f32;
+};
+
+struct FcDev {
+    DevBuf w[3], b[3];
+    int n[3] = {0, 0, 0}, k[3] = {0, 0, 0};
+};
+
+}  // namespace
+
+struct pngpd_model {
+    int device = 0;
+    int num_points = 0;
+    int k = 0;
+    int parts = 0;
+    bool loaded = false;
+    StackDev stn, trunk;
+    FcDev stn_fc, head_fc;
+};
+
+namespace {
+
+using pngpd::PackedStack;
+
+// folded conv/linear layer of unit `u`; n_out x n_in
+int fold_unit(const float* const* t, int u, int n_out, int n_in, bool has_bn, std::vector<float>& W,
+              std::vector<float>& b) {
+    const float* const* f = t + u * PNGPD_FIELDS;
+    if (!f[PNGPD_F_WEIGHT] || !f[PNGPD_F_BIAS])
+        return fail(PNGPD_ERR_INVALID, "weight table: unit %d has no weight/bias", u);
+    if (has_bn && (!f[PNGPD_F_BN_WEIGHT] || !f[PNGPD_F_BN_BIAS] || !f[PNGPD_F_BN_MEAN] || !f[PNGPD_F_BN_VAR]))
+        return fail(PNGPD_ERR_INVALID, "weight table: unit %d lacks BatchNorm tensors", u);
+    pngpd::fold_bn(f[PNGPD_F_WEIGHT], f[PNGPD_F_BIAS], has_bn ? f[PNGPD_F_BN_WEIGHT] : nullptr,
+                   f[PNGPD_F_BN_BIAS], f[PNGPD_F_BN_MEAN], f[PNGPD_F_BN_VAR], n_out, n_in, W, b);
+    return PNGPD_OK;
+}
+
+int load_stack(const float* const* t, int u_conv1, StackDev& d, std::vector<PackedStack>& keep,
+               hipStream_t s) {
+    std::vector<float> W1, b1, W2, b2, W3, b3;
+    int rc;
+    if ((rc = fold_unit(t, u_conv1 + 0, pngpd::C1, 3, true, W1, b1))) return rc;
+    if ((rc = fold_unit(t, u_conv1 + 1, pngpd::C2, pngpd::C1, true, W2, b2))) return rc;
+    if ((rc = fold_unit(t, u_conv1 + 2, pngpd::C3, pngpd::C2, true, W3, b3))) return rc;
+    keep.emplace_back();
+    PackedStack& p = keep.back();
+    pngpd::pack_stack(W1, b1, W2, b2, W3, b3, p);
+    HIP_TRY(d.w1tab.upload(p.w1tab.data(), p.w1tab.size() * 4, s));
+    HIP_TRY(d.b2p.upload(p.b2p.data(), p.b2p.size() * 4, s));
+    HIP_TRY(d.b3.upload(p.b3.data(), p.b3.size() * 4, s));
+    HIP_TRY(d.w2_bf16.upload(p.w2_bf16.data(), p.w2_bf16.size() * 2, s));
+    HIP_TRY(d.w3_bf16.upload(p.w3_bf16.data(), p.w3_bf16.size() * 2, s));
+    HIP_TRY(d.w2_f32.upload(p.w2_f32.data(), p.w2_f32.size() * 4, s));
+    HIP_TRY(d.w3_f32.upload(p.w3_f32.data(), p.w3_f32.size() * 4, s));
+    return PNGPD_OK;
+}
+
+int load_fc(const float* const* t, int u_fc1, int n_last, FcDev& d,
+            std::vector<std::vector<float>>& keep, hipStream_t s) {
+    const int n[3] = {512, 256, n_last}, k[3] = {1024, 512, 256};
+    for (int i = 0; i < 3; ++i) {
+        keep.emplace_back();
+        std::vector<float>& W = keep.back();
+        keep.emplace_back();
+        std::vector<float>& b = keep.back();
+        int rc = fold_unit(t, u_fc1 + i, n[i], k[i], i < 2, W, b);
+        if (rc) return rc;
+        HIP_TRY(d.w[i].upload(W.data(), W.size() * 4, s));
+        HIP_TRY(d.b[i].upload(b.data(), b.size() * 4, s));
+        d.n[i] = n[i];
+        d.k[i] = k[i];
+    }
+    return PNGPD_OK;
+}
+
+size_t round4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+struct Workspace {
+    float *pooled, *h512, *h256, *trans, *feat;
+    static size_t floats(int B) {
+        return (size_t)B * (1024 + 512 + 256 + 1024) + round4((size_t)B * 9);
+    }
+    Workspace(void* base, int B) {
+        float* p = (float*)base;
+        pooled = p; p += (size_t)B * 1024;
+        h512 = p;   p += (size_t)B * 512;
+        h256 = p;   p += (size_t)B * 256;
+        feat = p;   p += (size_t)B * 1024;
+        trans = p;
+    }
+};
+
+int run_fc_chain(const FcDev& fc, const float* in, Workspace& ws, float* out, int B, int tail,
+                 hipStream_t s) {
+    HIP_TRY(pngpd::launch_fc_f32(in, (const float*)fc.w[0].p, (const float*)fc.b[0].p, ws.h512, B,
+                                 fc.n[0], fc.k[0], 1, s));
+    HIP_TRY(pngpd::launch_fc_f32(ws.h512, (const float*)fc.w[1].p, (const float*)fc.b[1].p, ws.h256,
+                                 B, fc.n[1], fc.k[1], 1, s));
+    HIP_TRY(pngpd::launch_fc_tail(ws.h256, (const float*)fc.w[2].p, (const float*)fc.b[2].p, out, B,
+                                  fc.n[2], fc.k[2], tail, s));
+    return PNGPD_OK;
+}
+
+pngpd::ConvStackArgs stack_args(const StackDev& d, int precision, const float* x, int layout, int B,
+                                int P, const float* trans, float* pooled, int relu_out) {
+    pngpd::ConvStackArgs a;
+    a.x = x;
+    a.layout = layout;
+    a.B = B;
+    a.P = P;
+    a.w1tab = (const float4*)d.w1tab.p;
+    a.trans = trans;
+    a.w2p = precision == PNGPD_BF16 ? d.w2_bf16.p : d.w2_f32.p;
+    a.b2p = (const float*)d.b2p.p;
+    a.w3p = precision == PNGPD_BF16 ? d.w3_bf16.p : d.w3_f32.p;
+    a.b3 = (const float*)d.b3.p;
+    a.pooled = pooled;
+    a.relu_out = relu_out;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pngpd_last_error(void) { return g_last_error.c_str(); }
+
+int pngpd_abi_version(void) { return 1; }
+
+int pngpd_model_create(pngpd_model** out, int num_points, int k, int parts) {
+    if (!out) return fail(PNGPD_ERR_INVALID, "pngpd_model_create: out is NULL");
+    *out = nullptr;
+    if (num_points < 1) return fail(PNGPD_ERR_SHAPE, "num_points must be >= 1, got %d", num_points);
+    if (k < 1 || k > 16) return fail(PNGPD_ERR_SHAPE, "k must be in [1,16], got %d", k);
+    const int all = PNGPD_PART_STN | PNGPD_PART_TRUNK | PNGPD_PART_HEAD;
+    if (parts != PNGPD_PART_STN && parts != (PNGPD_PART_STN | PNGPD_PART_TRUNK) && parts != all)
+        return fail(PNGPD_ERR_INVALID, "parts must be STN, STN|TRUNK or STN|TRUNK|HEAD, got %d", parts);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    pngpd_model* m = new (std::nothrow) pngpd_model();
+    if (!m) return fail(PNGPD_ERR_INVALID, "out of host memory");
+    m->device = dev;
+    m->num_points = num_points;
+    m->k = k;
+    m->parts = parts;
+    *out = m;
+    return PNGPD_OK;
+}
+
+int pngpd_model_destroy(pngpd_model* m) {
+    delete m;
+    return PNGPD_OK;
+}
+
+int pngpd_model_load(pngpd_model* m, const float* const* host_tensors, int n_slots, void* stream) {
+    if (!m || !host_tensors) return fail(PNGPD_ERR_INVALID, "pngpd_model_load: NULL argument");
+    if (n_slots != PNGPD_SLOTS)
+        return fail(PNGPD_ERR_INVALID, "weight table must have %d slots, got %d", PNGPD_SLOTS, n_slots);
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != m->device)
+        return fail(PNGPD_ERR_STATE, "model lives on device %d but device %d is current", m->device, dev);
+    m->loaded = false;
+    std::vector<PackedStack> keep_stacks;
+    keep_stacks.reserve(2);
+    std::vector<std::vector<float>> keep_fc;
+    keep_fc.reserve(12);
+    int rc;
+    if (m->parts & PNGPD_PART_STN) {
+        if ((rc = load_stack(host_tensors, PNGPD_U_STN_CONV1, m->stn, keep_stacks, s))) return rc;
+        if ((rc = load_fc(host_tensors, PNGPD_U_STN_FC1, 9, m->stn_fc, keep_fc, s))) return rc;
+    }
+    if (m->parts & PNGPD_PART_TRUNK)
+        if ((rc = load_stack(host_tensors, PNGPD_U_FEAT_CONV1, m->trunk, keep_stacks, s))) return rc;
+    if (m->parts & PNGPD_PART_HEAD)
+        if ((rc = load_fc(host_tensors, PNGPD_U_FC1, m->k, m->head_fc, keep_fc, s))) return rc;
+    HIP_TRY(hipStreamSynchronize(s));   // staging vectors die at return
+    m->loaded = true;
+    return PNGPD_OK;
+}
+
+size_t pngpd_forward_workspace_bytes(const pngpd_model* m, int B) {
+    if (!m || B < 1) return 0;
+    return Workspace::floats(B) * sizeof(float);
+}
+
+int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
+                        int precision, float* logp_dev, float* trans_dev, float* feat_dev,
+                        void* workspace_dev, size_t workspace_bytes, void* stream) {
+    if (!m || !x_dev) return fail(PNGPD_ERR_INVALID, "pngpd_forward_infer: NULL model or input");
+    if (!m->loaded) return fail(PNGPD_ERR_STATE, "pngpd_forward_infer: weights not loaded");
+    if (B < 1) return fail(PNGPD_ERR_SHAPE, "batch must be >= 1, got %d", B);
+    if (P != m->num_points)
+        return fail(PNGPD_ERR_SHAPE, "input has %d points per candidate but the model was built for num_points=%d",
+                    P, m->num_points);
+    if (layout != PNGPD_LAYOUT_C3P && layout != PNGPD_LAYOUT_P3)
+        return fail(PNGPD_ERR_INVALID, "unknown layout %d", layout);
+    if (precision != PNGPD_FP32 && precision != PNGPD_BF16)
+        return fail(PNGPD_ERR_INVALID, "unknown precision %d", precision);
+    if (!workspace_dev || workspace_bytes < pngpd_forward_workspace_bytes(m, B))
+        return fail(PNGPD_ERR_WORKSPACE, "workspace of %zu bytes is smaller than the %zu needed for B=%d",
+                    workspace_bytes, pngpd_forward_workspace_bytes(m, B), B);
+    if (logp_dev && !(m->parts & PNGPD_PART_HEAD))
+        return fail(PNGPD_ERR_STATE, "log-probabilities requested from a model without a head");
+    if (feat_dev && !(m->parts & PNGPD_PART_TRUNK))
+        return fail(PNGPD_ERR_STATE, "global feature requested from a model without a trunk");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(workspace_dev, B);
+    auto launch_stack = precision == PNGPD_BF16 ? pngpd::launch_conv_stack_bf16 : pngpd::launch_conv_stack_f32;
+
+    // STN3d: conv stack (ReLU after the max), then the 1024-512-256-9 regressor + identity
+    float* trans = trans_dev ? trans_dev : ws.trans;
+    HIP_TRY(launch_stack(stack_args(m->stn, precision, x_dev, layout, B, P, nullptr, ws.pooled, 1), s));
+    int rc = run_fc_chain(m->stn_fc, ws.pooled, ws, trans, B, pngpd::FC_TAIL_ADD_IDENTITY, s);
+    if (rc) return rc;
+    if (!(m->parts & PNGPD_PART_TRUNK)) return PNGPD_OK;
+
+    // PointNetfeat: points times trans, conv stack without the last ReLU
+    float* feat = feat_dev ? feat_dev : ws.feat;
+    HIP_TRY(launch_stack(stack_args(m->trunk, precision, x_dev, layout, B, P, trans, feat, 0), s));
+    if (!(m->parts & PNGPD_PART_HEAD) || !logp_dev) return PNGPD_OK;
+
+    // PointNetCls head + log_softmax
+    return run_fc_chain(m->head_fc, feat, ws, logp_dev, B, pngpd::FC_TAIL_LOG_SOFTMAX, s);
+}
+
+int pngpd_profile_conv_stack(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
+                             int precision, int which, int iters, void* workspace_dev,
+                             size_t workspace_bytes, float* mean_ms_out, void* stream) {
+    if (!m || !x_dev || !mean_ms_out) return fail(PNGPD_ERR_INVALID, "pngpd_profile_conv_stack: NULL argument");
+    if (!m->loaded) return fail(PNGPD_ERR_STATE, "pngpd_profile_conv_stack: weights not loaded");
+    if (B < 1 || P != m->num_points || iters < 1) return fail(PNGPD_ERR_SHAPE, "pngpd_profile_conv_stack: bad B/P/iters");
+    if (which != 0 && !(m->parts & PNGPD_PART_TRUNK)) return fail(PNGPD_ERR_STATE, "model has no trunk");
+    if (!workspace_dev || workspace_bytes < pngpd_forward_workspace_bytes(m, B))
+        return fail(PNGPD_ERR_WORKSPACE, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(workspace_dev, B);
+    auto launch_stack = precision == PNGPD_BF16 ? pngpd::launch_conv_stack_bf16 : pngpd::launch_conv_stack_f32;
+    const StackDev& d = which == 0 ? m->stn : m->trunk;
+    pngpd::ConvStackArgs a = stack_args(d, precision, x_dev, layout, B, P, nullptr, ws.pooled, which == 0);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(launch_stack(a, s));   // warm
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) HIP_TRY(launch_stack(a, s));
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *mean_ms_out = ms / iters;
+    return PNGPD_OK;
+}
+
+int pngpd_score(const float* logp_dev, int B, int k, float* probs_dev, int64_t* pred_dev, void* stream) {
+    if (!logp_dev || !probs_dev || !pred_dev) return fail(PNGPD_ERR_INVALID, "pngpd_score: NULL argument");
+    if (B < 1 || k < 1) return fail(PNGPD_ERR_SHAPE, "pngpd_score: B=%d k=%d", B, k);
+    HIP_TRY(pngpd::launch_score(logp_dev, B, k, probs_dev, pred_dev, (hipStream_t)stream));
+    return PNGPD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// Internal launch interface between the C-ABI layer (api.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace pngpd {
+
+constexpr int C1 = 64;     // conv1 output channels
+constexpr int C2 = 128;    // conv2 output channels
+constexpr int C3 = 1024;   // conv3 output channels
+
+// Sizes of the packed conv-stack weight images (see pack.cpp for the element order).
+constexpr size_t W2P_BF16_BYTES = (size_t)C2 * C1 * 2;      // 16 KiB
+constexpr size_t W3P_BF16_BYTES = (size_t)C3 * C2 * 2;      // 256 KiB
+constexpr size_t W2P_F32_BYTES = (size_t)C2 * C1 * 4;       // 32 KiB
+constexpr size_t W3P_F32_BYTES = (size_t)C3 * C2 * 4;       // 512 KiB
+constexpr int B2P_FLOATS = 4 * 2 * 16;                      // bias of conv2 in accumulator order
+
+// One fused "3 -> 64 -> 128 -> 1024 -> max over points" stack.
+struct ConvStackArgs {
+    const float* x;        // candidate points, layout `layout`
+    int layout;            // PNGPD_LAYOUT_*
+    int B;                 // candidates
+    int P;                 // points per candidate
+    const float4* w1tab;   // [64] {w0, w1, w2, bias}: BN-folded conv1
+    const float* trans;    // [B,9] per-candidate 3x3 applied to the points first, or nullptr
+    const void* w2p;       // packed BN-folded conv2 weights (bf16 or f32 image)
+    const float* b2p;      // [4][2][16] conv2 bias in accumulator-register order
+    const void* w3p;       // packed BN-folded conv3 weights (bf16 or f32 image)
+    const float* b3;       // [1024] BN-folded conv3 bias
+    float* pooled;         // [B,1024] max over points (+bias, optional ReLU)
+    int relu_out;          // 1: ReLU after the max (STN), 0: none (trunk)
+};
+
+hipError_t launch_conv_stack_bf16(const ConvStackArgs& a, hipStream_t s);
+hipError_t launch_conv_stack_f32(const ConvStackArgs& a, hipStream_t s);
+
+// Y[M,N] = act(X[M,K] * W[N,K]^T + b[N]); fp32 MFMA.  N % 64 == 0, K % 32 == 0.
+hipError_t launch_fc_f32(const float* X, const float* W, const float* b, float* Y, int M, int N,
+                         int K, int relu, hipStream_t s);
+
+enum { FC_TAIL_PLAIN = 0, FC_TAIL_ADD_IDENTITY = 1, FC_TAIL_LOG_SOFTMAX = 2 };
+// Y[M,N] = tail(X[M,K] * W[N,K]^T + b[N]) for tiny N (<= 16), K % 256 == 0.
+hipError_t launch_fc_tail(const float* X, const float* W, const float* b, float* Y, int M, int N,
+                          int K, int tail, hipStream_t s);
+
+hipError_t launch_score(const float* logp, int B, int k, float* probs, int64_t* pred,
+                        hipStream_t s);
+
+}  // namespace pngpd

@@ -1,0 +1,239 @@
+"""Drop-in replacements for STN3d / PointNetfeat / PointNetCls (reference model/pointnet.py:8-45,
+122-152, 174-190) whose forward runs hand-written gfx950 kernels through the C ABI in
+include/pngpd.h.
+
+What is preserved from the reference: constructor arguments (num_points, input_chann, k /
+global_feat), sub-module names and registration order - hence the 74 state_dict keys, shapes and
+their order - forward signatures and return values, .eval()/.train()/.to()/.cuda()/parameters().
+
+What is different: there is no CPU execution path.  The parameters live in ordinary
+Conv1d/Linear/BatchNorm1d containers, but forward() never calls them; it hands device pointers to
+the library.  A CPU tensor, or a missing libpngpd.so, raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_DEFAULT_PRECISION = os.environ.get("PNGPD_PRECISION", "fp32")
+
+
+class _Handle:
+    """Owns one pngpd_model (device weights) and the per-batch-size workspaces."""
+
+    def __init__(self, device: torch.device, num_points: int, k: int, parts: int):
+        self.lib = _lib.load()
+        self.device = device
+        self.ptr = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(self.lib.pngpd_model_create(ctypes.byref(self.ptr), num_points, k, parts))
+        self.signature = None
+        self._ws = {}
+
+    def workspace(self, B: int) -> torch.Tensor:
+        ws = self._ws.get(B)
+        if ws is None:
+            nbytes = self.lib.pngpd_forward_workspace_bytes(self.ptr, B)
+            if len(self._ws) > 8:
+                self._ws.clear()
+            ws = self._ws[B] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return ws
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.pngpd_model_destroy(self.ptr)
+                self.ptr = ctypes.c_void_p()
+        except Exception:
+            pass
+
+
+class _HipBacked(nn.Module):
+    """Shared plumbing: weight-table assembly, repack-on-change, launch."""
+
+    _PARTS = 0
+    precision = _DEFAULT_PRECISION  # "fp32" (exact-f32 MFMA) or "bf16"; instance attribute overrides
+
+    # unit name (C ABI order) -> (layer, batchnorm or None); filled by subclasses
+    def _units(self) -> dict:
+        raise NotImplementedError
+
+    def _num_classes(self) -> int:
+        return 2   # unused by models without a head
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_hip", None)   # device handles never travel through pickle / deepcopy
+        return state
+
+    def _tensors(self):
+        for layer, bn in self._units().values():
+            yield layer.weight
+            yield layer.bias
+            if bn is not None:
+                yield from (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+    def _handle(self, device: torch.device) -> _Handle:
+        h = self.__dict__.get("_hip")
+        if h is None or h.device != device:
+            h = self.__dict__["_hip"] = _Handle(device, self.num_points, self._num_classes(), self._PARTS)
+        sig = tuple((t.data_ptr(), t._version) for t in self._tensors())
+        if h.signature != sig:
+            self._upload(h)
+            h.signature = sig
+        return h
+
+    def _upload(self, h: _Handle) -> None:
+        units = self._units()
+        table = (ctypes.c_void_p * _lib.SLOTS)()
+        keep = []
+        for ui, uname in enumerate(_lib.UNITS):
+            if uname not in units:
+                continue
+            layer, bn = units[uname]
+            fields = [layer.weight, layer.bias]
+            fields += [bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [None] * 4
+            for fi, t in enumerate(fields):
+                if t is None:
+                    continue
+                host = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+                keep.append(host)
+                table[ui * len(_lib.FIELDS) + fi] = host.data_ptr()
+        with torch.cuda.device(h.device):
+            stream = torch.cuda.current_stream(h.device).cuda_stream
+            _lib.check(h.lib.pngpd_model_load(h.ptr, table, _lib.SLOTS, ctypes.c_void_p(stream)))
+
+    def _check_input(self, x: torch.Tensor, layout: int):
+        if not isinstance(x, torch.Tensor) or x.dim() != 3:
+            raise ValueError("expected a 3-D tensor of candidate points")
+        if not x.is_cuda:
+            raise RuntimeError("pointnetgpd_amd runs on MI355X only: move the module and its input to a "
+                               "ROCm device (there is no CPU path)")
+        if self.training:
+            raise RuntimeError("train-mode forward goes through pointnetgpd_amd.training (batch statistics); "
+                               "call .eval() for inference")
+        chan_dim, pts_dim = (1, 2) if layout == _lib.LAYOUT_C3P else (2, 1)
+        if x.shape[chan_dim] != 3:
+            raise ValueError(f"input_chann must be 3, got {x.shape[chan_dim]}")
+        if x.shape[pts_dim] != self.num_points:
+            raise ValueError(f"input has {x.shape[pts_dim]} points per candidate but the module was built "
+                             f"with num_points={self.num_points}")
+        return x.detach().to(torch.float32).contiguous()
+
+    def _infer(self, x: torch.Tensor, layout: int, want_logp: bool, want_feat: bool):
+        x = self._check_input(x, layout)
+        B = x.shape[0]
+        dev = x.device
+        h = self._handle(dev)
+        prec = _lib.PRECISIONS[str(self.precision).lower()]
+        k = self._num_classes()
+        logp = torch.empty((B, k), dtype=torch.float32, device=dev) if want_logp else None
+        feat = torch.empty((B, 1024), dtype=torch.float32, device=dev) if want_feat else None
+        trans = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
+        ws = h.workspace(B)
+
+        def p(t):
+            return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(h.lib.pngpd_forward_infer(h.ptr, p(x), layout, B, self.num_points, prec, p(logp), p(trans),
+                                                 p(feat), p(ws), ws.numel(), ctypes.c_void_p(stream)))
+        return logp, trans, feat
+
+
+def _conv(cin, cout):
+    return nn.Conv1d(cin, cout, 1)
+
+
+class STN3d(_HipBacked):
+    """3x3 input transform regressor; forward(x[B,3,P]) -> [B,3,3]."""
+
+    _PARTS = _lib.PART_STN
+
+    def __init__(self, num_points=2500, input_chann=3):
+        super().__init__()
+        self.num_points = num_points
+        self.conv1, self.conv2, self.conv3 = _conv(input_chann, 64), _conv(64, 128), _conv(128, 1024)
+        self.mp1 = nn.MaxPool1d(num_points)
+        self.fc1, self.fc2, self.fc3 = nn.Linear(1024, 512), nn.Linear(512, 256), nn.Linear(256, 9)
+        self.relu = nn.ReLU()
+        for i, c in enumerate((64, 128, 1024, 512, 256), start=1):
+            setattr(self, f"bn{i}", nn.BatchNorm1d(c))
+
+    def _stn_units(self):
+        return {"stn_conv1": (self.conv1, self.bn1), "stn_conv2": (self.conv2, self.bn2),
+                "stn_conv3": (self.conv3, self.bn3), "stn_fc1": (self.fc1, self.bn4),
+                "stn_fc2": (self.fc2, self.bn5), "stn_fc3": (self.fc3, None)}
+
+    _units = _stn_units
+
+    def forward(self, x):
+        return self._infer(x, _lib.LAYOUT_C3P, False, False)[1]
+
+
+class PointNetfeat(_HipBacked):
+    """Global feature extractor; forward(x[B,3,P]) -> (feat[B,1024], trans[B,3,3])."""
+
+    _PARTS = _lib.PART_STN | _lib.PART_TRUNK
+
+    def __init__(self, num_points=2500, input_chann=3, global_feat=True):
+        super().__init__()
+        self.stn = STN3d(num_points=num_points, input_chann=input_chann)
+        self.conv1, self.conv2, self.conv3 = _conv(input_chann, 64), _conv(64, 128), _conv(128, 1024)
+        for i, c in enumerate((64, 128, 1024), start=1):
+            setattr(self, f"bn{i}", nn.BatchNorm1d(c))
+        self.mp1 = nn.MaxPool1d(num_points)
+        self.num_points = num_points
+        self.global_feat = global_feat
+
+    def _feat_units(self):
+        u = self.stn._stn_units()
+        u.update({"feat_conv1": (self.conv1, self.bn1), "feat_conv2": (self.conv2, self.bn2),
+                  "feat_conv3": (self.conv3, self.bn3)})
+        return u
+
+    _units = _feat_units
+
+    def forward(self, x):
+        if not self.global_feat:
+            raise NotImplementedError("global_feat=False (per-point features for PointNetDenseCls) is not "
+                                      "part of the grasp-scoring path")
+        _, trans, feat = self._infer(x, _lib.LAYOUT_C3P, False, True)
+        return feat, trans
+
+
+class PointNetCls(_HipBacked):
+    """Grasp classifier; forward(x[B,3,P]) -> (log_probs[B,k], trans[B,3,3])."""
+
+    _PARTS = _lib.PART_STN | _lib.PART_TRUNK | _lib.PART_HEAD
+
+    def __init__(self, num_points=2500, input_chann=3, k=2):
+        super().__init__()
+        self.num_points = num_points
+        self.feat = PointNetfeat(num_points, input_chann=input_chann, global_feat=True)
+        self.fc1, self.fc2, self.fc3 = nn.Linear(1024, 512), nn.Linear(512, 256), nn.Linear(256, k)
+        self.bn1, self.bn2 = nn.BatchNorm1d(512), nn.BatchNorm1d(256)
+        self.relu = nn.ReLU()
+
+    def _units(self):
+        u = self.feat._feat_units()
+        u.update({"fc1": (self.fc1, self.bn1), "fc2": (self.fc2, self.bn2), "fc3": (self.fc3, None)})
+        return u
+
+    def _num_classes(self) -> int:
+        return self.fc3.out_features
+
+    def forward(self, x):
+        logp, trans, _ = self._infer(x, _lib.LAYOUT_C3P, True, False)
+        return logp, trans
+
+    def forward_points(self, points, return_feat=False):
+        """Same network on points laid out [B,P,3] (what the in-gripper crop produces)."""
+        logp, trans, feat = self._infer(points, _lib.LAYOUT_P3, True, return_feat)
+        return (logp, trans, feat) if return_feat else (logp, trans)

@@ -1,0 +1,175 @@
+"""GPU parity of the HIP forward path (through the C ABI) against the reference's golden vectors
+and against the CPU oracle on fresh seeded inputs.
+
+Tolerances: exact-f32 MFMA path 1e-4 absolute on log-probabilities and on the 3x3 transform;
+bf16 path 2e-2 absolute on log-probabilities; arg-max agreement on candidates whose two best
+classes are further apart than the tolerance.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pointnet_oracle as po
+from pointnetgpd_amd import synth
+from pointnetgpd_amd.pointnet import PointNetCls, PointNetfeat, STN3d
+from pointnetgpd_amd.scoring import score_candidates, test_network as hip_test_network
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+EVAL_FILES = sorted(glob.glob(os.path.join(GOLDEN, "eval_*.npz")))
+FP32_ATOL = 1e-4
+BF16_ATOL = 2e-2
+
+
+def hip_model(P, k, seed, scale, precision, gain=2.0):
+    m = PointNetCls(P, 3, k)
+    m.load_state_dict(synth.torch_state_dict(seed, k, scale, gain), strict=True)
+    m = m.cuda().eval()
+    m.precision = precision
+    return m
+
+
+def top1_agree(logp, ref_logp, tol):
+    ref_sorted = np.sort(ref_logp, axis=1)
+    decided = (ref_sorted[:, -1] - ref_sorted[:, -2]) > 2 * tol
+    return (logp.argmax(1) == ref_logp.argmax(1))[decided].all(), int(decided.sum())
+
+
+@pytest.mark.parametrize("path", EVAL_FILES, ids=[os.path.basename(p)[5:-4] for p in EVAL_FILES])
+def test_fp32_matches_reference_golden(path):
+    d = np.load(path)
+    P, k, seed, B = (int(v) for v in d["meta"])
+    m = hip_model(P, k, seed, float(d["input_scale"]), "fp32", float(d["gain"]))
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, str(d["kind"]))).cuda()
+    logp, trans = m(x)
+    feat, trans2 = m.feat(x)
+    stn_trans = m.feat.stn(x)
+    torch.cuda.synchronize()
+    err = np.abs(logp.cpu().numpy() - d["logp"]).max()
+    print(f"fp32 max |dlogp| = {err:.3e}")
+    assert err <= FP32_ATOL
+    np.testing.assert_allclose(trans.cpu().numpy(), d["trans"], rtol=0, atol=FP32_ATOL)
+    np.testing.assert_allclose(trans2.cpu().numpy(), d["trans"], rtol=0, atol=FP32_ATOL)
+    np.testing.assert_allclose(stn_trans.cpu().numpy(), d["trans"], rtol=0, atol=FP32_ATOL)
+    np.testing.assert_allclose(feat.cpu().numpy(), d["feat"], rtol=2e-5, atol=FP32_ATOL)
+    ok, n = top1_agree(logp.cpu().numpy(), d["logp"], FP32_ATOL)
+    assert ok and n > 0
+
+
+@pytest.mark.parametrize("path", EVAL_FILES, ids=[os.path.basename(p)[5:-4] for p in EVAL_FILES])
+def test_bf16_matches_reference_golden(path):
+    d = np.load(path)
+    P, k, seed, B = (int(v) for v in d["meta"])
+    m = hip_model(P, k, seed, float(d["input_scale"]), "bf16", float(d["gain"]))
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, str(d["kind"]))).cuda()
+    logp, trans = m(x)
+    torch.cuda.synchronize()
+    err = np.abs(logp.cpu().numpy() - d["logp"]).max()
+    print(f"bf16 max |dlogp| = {err:.3e}, max |dtrans| = {np.abs(trans.cpu().numpy() - d['trans']).max():.3e}")
+    assert err <= BF16_ATOL
+    ok, _ = top1_agree(logp.cpu().numpy(), d["logp"], BF16_ATOL)
+    assert ok
+
+
+@pytest.mark.parametrize("B", [1, 3, 64])
+@pytest.mark.parametrize("precision,tol", [("fp32", FP32_ATOL), ("bf16", BF16_ATOL)])
+def test_against_oracle_fresh_inputs(B, precision, tol):
+    P, k, seed = 750, 2, 31
+    sd = synth.torch_state_dict(seed, k, 0.02)
+    oracle = po.build_cls(P, k, sd)
+    m = hip_model(P, k, seed, 0.02, precision)
+    x = torch.from_numpy(synth.candidate_points(seed + B, B, P, "gripper"))
+    with torch.no_grad():
+        ref_logp, ref_trans = oracle(x)
+    logp, trans = m(x.cuda())
+    err = (logp.cpu() - ref_logp).abs().max().item()
+    print(f"{precision} B={B}: max |dlogp| = {err:.3e}")
+    assert err <= tol
+    assert (trans.cpu() - ref_trans).abs().max().item() <= (tol if precision == "fp32" else 5e-2)
+    ok, _ = top1_agree(logp.cpu().numpy(), ref_logp.numpy(), tol)
+    assert ok
+
+
+def test_points_layout_is_bitwise_equivalent():
+    m = hip_model(750, 2, 33, 1.0, "bf16", 1.7)
+    x = torch.from_numpy(synth.candidate_points(33, 5, 750, "normal")).cuda()
+    a, ta = m(x)
+    b, tb = m.forward_points(x.transpose(1, 2).contiguous())
+    assert torch.equal(a, b) and torch.equal(ta, tb)
+
+
+def test_scoring_shim_matches_test_network_semantics():
+    """Row i of the batched score equals main_test.py:73-83 applied to candidate i."""
+    d = np.load(EVAL_FILES[0])
+    P, k, seed, B = (int(v) for v in d["meta"])
+    m = hip_model(P, k, seed, float(d["input_scale"]), "fp32", float(d["gain"]))
+    x = synth.candidate_points(seed, B, P, str(d["kind"]))
+    pts = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).cuda()
+    pred, probs, _ = score_candidates(m, pts)
+    np.testing.assert_allclose(probs.cpu().numpy(), d["probs"], atol=FP32_ATOL)
+    np.testing.assert_array_equal(pred.cpu().numpy(), d["pred"])
+    p1, pr1 = hip_test_network(m, x[2].T.astype(np.float64))
+    assert pr1.shape == (1, k) and int(p1[0]) == int(d["pred"][2])
+    np.testing.assert_allclose(pr1[0], d["probs"][2], atol=FP32_ATOL)
+
+
+def test_wrong_point_count_is_rejected():
+    m = hip_model(750, 2, 1, 1.0, "fp32")
+    with pytest.raises(ValueError, match="num_points"):
+        m(torch.zeros(2, 3, 500, device="cuda"))
+
+
+def test_weights_repacked_after_in_place_update():
+    m = hip_model(750, 2, 35, 1.0, "fp32")
+    x = torch.from_numpy(synth.candidate_points(35, 2, 750, "normal")).cuda()
+    a, _ = m(x)
+    with torch.no_grad():
+        m.fc3.bias.add_(torch.tensor([0.5, -0.5], device="cuda"))
+    b, _ = m(x)
+    assert not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_size_properties(precision):
+    """B=4096 (bf16) / 512 (fp32), P=750: results do not depend on batch position, batch size or
+    on the order of the points inside a candidate (the max-pool is symmetric) - bit for bit."""
+    B = 4096 if precision == "bf16" else 512
+    P, seed = 750, 41
+    m = hip_model(P, 2, seed, 0.02, precision)
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, "gripper")).cuda()
+    logp, trans = m(x)
+    assert torch.isfinite(logp).all()
+    assert torch.allclose(logp.exp().sum(1), torch.ones(B, device="cuda"), atol=1e-5)
+    idx = torch.tensor([0, 1, B // 2, B - 1], device="cuda")
+    sub, sub_t = m(x[idx].contiguous())
+    assert torch.equal(sub, logp[idx]) and torch.equal(sub_t, trans[idx])
+    perm = torch.randperm(P, generator=torch.Generator().manual_seed(0)).cuda()
+    shuf, _ = m(x[idx][:, :, perm].contiguous())
+    assert torch.equal(shuf, logp[idx])
+    # oracle on a handful of rows of the big batch
+    oracle = po.build_cls(P, 2, synth.torch_state_dict(seed, 2, 0.02))
+    with torch.no_grad():
+        ref, _ = oracle(x[idx].cpu())
+    tol = FP32_ATOL if precision == "fp32" else BF16_ATOL
+    assert (logp[idx].cpu() - ref).abs().max().item() <= tol
+
+
+def test_standalone_submodules():
+    sd = synth.torch_state_dict(37, 2, 1.0, 1.7)
+    x = torch.from_numpy(synth.candidate_points(37, 4, 750, "normal"))
+    oracle = po.build_cls(750, 2, sd)
+    with torch.no_grad():
+        ref_feat, ref_trans = oracle.feat(x)
+    stn = STN3d(750, 3)
+    stn.load_state_dict({k[len("feat.stn."):]: v for k, v in sd.items() if k.startswith("feat.stn.")})
+    feat = PointNetfeat(750, 3)
+    feat.load_state_dict({k[len("feat."):]: v for k, v in sd.items() if k.startswith("feat.")})
+    t = stn.cuda().eval()(x.cuda())
+    f, t2 = feat.cuda().eval()(x.cuda())
+    assert (t.cpu() - ref_trans).abs().max().item() <= FP32_ATOL
+    assert (t2.cpu() - ref_trans).abs().max().item() <= FP32_ATOL
+    np.testing.assert_allclose(f.cpu().numpy(), ref_feat.numpy(), rtol=2e-5, atol=FP32_ATOL)
