@@ -120,6 +120,61 @@ int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, in
 int pngpd_score(const float* logp_dev, int B, int k, float* probs_dev, int64_t* pred_dev,
                 void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * In-gripper crop: collect_pc / check_collision_square (apps/kinect2grasp.py:377-438, 299-344,
+ * way="p_open").  float64 arithmetic in the reference's operation order; the index set is
+ * bit-exact and ascending (np.where order, :340).
+ *
+ *   scene_dev   float32 [S,3]   scene cloud (apps/kinect2grasp.py:159)
+ *   grasps_dev  float64 [G,5,3] the array collect_pc reshapes (:389): row 4 bottom centre,
+ *                               rows 1,2,3 approach / binormal / minor axis (not yet unit length)
+ *   limits      6 host doubles  ylo, yhi, zlo, zhi, xlo, xhi = p[1].y, p[2].y, p[4].z, p[1].z,
+ *                               p[8].x, p[4].x of the gripper corner table (:323, 332-337)
+ *
+ * Call order: pngpd_crop_count -> (read offsets_dev[G] = total, size idx_dev) -> pngpd_crop_emit
+ * -> pngpd_crop_gather.  The three calls share `workspace_dev` (normalised frames + one bit per
+ * (grasp, point)); it must stay untouched between them.
+ * ------------------------------------------------------------------------------------------ */
+size_t pngpd_crop_workspace_bytes(int S, int G);
+
+/* cnt_dev int32 [G] = points inside each gripper; offsets_dev int64 [G+1] = exclusive prefix. */
+int pngpd_crop_count(const float* scene_dev, int S, const double* grasps_dev, int G,
+                     const double* limits, void* workspace_dev, size_t workspace_bytes,
+                     int32_t* cnt_dev, int64_t* offsets_dev, void* stream);
+
+/* idx_dev int32 [idx_capacity]: for grasp g the ascending scene indices sit at
+ * offsets[g] .. offsets[g+1]-1 (in_ind_, :413); entries at or beyond idx_capacity are dropped.
+ * pts_g_dev (optional) float64 [idx_capacity,3]: the same points in the gripper frame
+ * (in_ind_points_, :423). */
+int pngpd_crop_emit(const float* scene_dev, int S, int G, const void* workspace_dev,
+                    size_t workspace_bytes, const int64_t* offsets_dev, int32_t* idx_dev,
+                    int64_t idx_capacity, double* pts_g_dev, void* stream);
+
+/*
+ * Subsample / pad every grasp to P points, `repeat` times (apps/kinect2grasp.py:746-774), and
+ * write the network input float32 [G*repeat, P, 3] (gripper frame, rounded from float64 like
+ * torch.FloatTensor(local_pc), main_test.py:76).  Grasps with fewer than min_points (20, :746)
+ * points get valid_dev[g] = 0 and zeros.
+ * Selection: sel_dev int32 [G*repeat, P] gives, per output point, the position inside the
+ * grasp's index list (what np.random.choice returned in the reference); NULL = draw on the
+ * device with the library's counter-based generator keyed by (seed, grasp, repeat, i): without
+ * replacement when cnt >= P, with replacement otherwise.  sel_out_dev (optional) receives the
+ * positions used.
+ */
+int pngpd_crop_gather(const float* scene_dev, int S, int G, const void* workspace_dev,
+                      size_t workspace_bytes, const int32_t* idx_dev, const int64_t* offsets_dev,
+                      const int32_t* cnt_dev, int repeat, int P, int min_points,
+                      const int32_t* sel_dev, uint64_t seed, float* pts_out_dev,
+                      int32_t* sel_out_dev, uint8_t* valid_dev, void* stream);
+
+/*
+ * Repeat vote (apps/kinect2grasp.py:799-817): pred_dev int64 [G*repeat], probs_dev [G*repeat,k]
+ * -> label_dev int32 [G] (mode, smallest label on ties), score_dev float32 [G] (mean probability
+ * of class k-1 over the repeats that agree with the vote).  valid_dev[g] == 0 gives (0, 0.0).
+ */
+int pngpd_vote(const int64_t* pred_dev, const float* probs_dev, const uint8_t* valid_dev, int G,
+               int repeat, int k, int32_t* label_dev, float* score_dev, void* stream);
+
 /*
  * Diagnostic: time the fused conv-stack kernel alone.  Launches the STN stack (which = 0) or the
  * trunk stack (which = 1; uses an identity transform) `iters` times on `stream` between two HIP

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpngpd.so")
@@ -40,6 +40,14 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "pngpd_profile_conv_stack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                          c_size_t, POINTER(c_float), c_void_p]),
+    "pngpd_crop_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pngpd_crop_count": (c_int, [c_void_p, c_int, c_void_p, c_int, POINTER(c_double), c_void_p, c_size_t, c_void_p,
+                                 c_void_p, c_void_p]),
+    "pngpd_crop_emit": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int64, c_void_p,
+                                c_void_p]),
+    "pngpd_crop_gather": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_int, c_int, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pngpd_vote": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pngpd_score": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 

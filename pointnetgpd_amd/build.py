@@ -81,7 +81,7 @@ def build_oracle_c(force: bool = False) -> str:
         return ""
     os.makedirs(os.path.dirname(ORACLE_C_PATH), exist_ok=True)
     if force or _newer(ORACLE_C_PATH, [src]):
-        _run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", src, "-o", ORACLE_C_PATH, "-lm"])
+        _run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", src, "-o", ORACLE_C_PATH, "-lm"])
     return ORACLE_C_PATH
 
 

@@ -302,6 +302,76 @@ int pngpd_profile_conv_stack(const pngpd_model* m, const float* x_dev, int layou
     return PNGPD_OK;
 }
 
+// crop workspace: [G,12] f64 frames, then [G, Wp] u64 mask (frames region rounded up to 256 B)
+static size_t crop_frames_bytes(int G) { return ((size_t)G * 12 * sizeof(double) + 255) & ~(size_t)255; }
+
+size_t pngpd_crop_workspace_bytes(int S, int G) {
+    if (S < 1 || G < 1) return 0;
+    return crop_frames_bytes(G) + (size_t)G * pngpd::crop_words_per_grasp(S) * sizeof(unsigned long long);
+}
+
+static int crop_ws_check(int S, int G, const void* ws, size_t bytes) {
+    if (S < 1 || G < 1) return fail(PNGPD_ERR_SHAPE, "crop: S=%d G=%d", S, G);
+    if (!ws || bytes < pngpd_crop_workspace_bytes(S, G))
+        return fail(PNGPD_ERR_WORKSPACE, "crop workspace of %zu bytes is smaller than the %zu needed for S=%d G=%d",
+                    bytes, pngpd_crop_workspace_bytes(S, G), S, G);
+    return PNGPD_OK;
+}
+
+int pngpd_crop_count(const float* scene_dev, int S, const double* grasps_dev, int G, const double* limits,
+                     void* workspace_dev, size_t workspace_bytes, int32_t* cnt_dev, int64_t* offsets_dev,
+                     void* stream) {
+    if (!scene_dev || !grasps_dev || !limits || !cnt_dev || !offsets_dev)
+        return fail(PNGPD_ERR_INVALID, "pngpd_crop_count: NULL argument");
+    int rc = crop_ws_check(S, G, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    pngpd::CropLimits L{limits[0], limits[1], limits[2], limits[3], limits[4], limits[5]};
+    double* frames = (double*)workspace_dev;
+    auto* mask = (unsigned long long*)((char*)workspace_dev + crop_frames_bytes(G));
+    HIP_TRY(pngpd::launch_crop_count(scene_dev, S, grasps_dev, G, L, frames, mask, cnt_dev,
+                                     (long long*)offsets_dev, (hipStream_t)stream));
+    return PNGPD_OK;
+}
+
+int pngpd_crop_emit(const float* scene_dev, int S, int G, const void* workspace_dev, size_t workspace_bytes,
+                    const int64_t* offsets_dev, int32_t* idx_dev, int64_t idx_capacity, double* pts_g_dev,
+                    void* stream) {
+    if (!scene_dev || !offsets_dev || !idx_dev) return fail(PNGPD_ERR_INVALID, "pngpd_crop_emit: NULL argument");
+    if (idx_capacity < 0) return fail(PNGPD_ERR_SHAPE, "pngpd_crop_emit: negative capacity");
+    int rc = crop_ws_check(S, G, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    const double* frames = (const double*)workspace_dev;
+    auto* mask = (const unsigned long long*)((const char*)workspace_dev + crop_frames_bytes(G));
+    HIP_TRY(pngpd::launch_crop_emit(scene_dev, S, G, frames, mask, (const long long*)offsets_dev, idx_dev,
+                                    idx_capacity, pts_g_dev, (hipStream_t)stream));
+    return PNGPD_OK;
+}
+
+int pngpd_crop_gather(const float* scene_dev, int S, int G, const void* workspace_dev, size_t workspace_bytes,
+                      const int32_t* idx_dev, const int64_t* offsets_dev, const int32_t* cnt_dev, int repeat,
+                      int P, int min_points, const int32_t* sel_dev, uint64_t seed, float* pts_out_dev,
+                      int32_t* sel_out_dev, uint8_t* valid_dev, void* stream) {
+    if (!scene_dev || !idx_dev || !offsets_dev || !cnt_dev || !pts_out_dev || !valid_dev)
+        return fail(PNGPD_ERR_INVALID, "pngpd_crop_gather: NULL argument");
+    if (repeat < 1 || P < 1 || min_points < 1)
+        return fail(PNGPD_ERR_SHAPE, "pngpd_crop_gather: repeat=%d P=%d min_points=%d", repeat, P, min_points);
+    int rc = crop_ws_check(S, G, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    HIP_TRY(pngpd::launch_crop_gather(scene_dev, (const double*)workspace_dev, idx_dev, (const long long*)offsets_dev,
+                                      cnt_dev, G, repeat, P, min_points, sel_dev, seed, pts_out_dev, sel_out_dev,
+                                      valid_dev, (hipStream_t)stream));
+    return PNGPD_OK;
+}
+
+int pngpd_vote(const int64_t* pred_dev, const float* probs_dev, const uint8_t* valid_dev, int G, int repeat, int k,
+               int32_t* label_dev, float* score_dev, void* stream) {
+    if (!pred_dev || !probs_dev || !label_dev || !score_dev) return fail(PNGPD_ERR_INVALID, "pngpd_vote: NULL argument");
+    if (G < 1 || repeat < 1 || k < 2 || k > 16) return fail(PNGPD_ERR_SHAPE, "pngpd_vote: G=%d repeat=%d k=%d", G, repeat, k);
+    HIP_TRY(pngpd::launch_vote((const long long*)pred_dev, probs_dev, valid_dev, G, repeat, k, label_dev, score_dev,
+                               (hipStream_t)stream));
+    return PNGPD_OK;
+}
+
 int pngpd_score(const float* logp_dev, int B, int k, float* probs_dev, int64_t* pred_dev, void* stream) {
     if (!logp_dev || !probs_dev || !pred_dev) return fail(PNGPD_ERR_INVALID, "pngpd_score: NULL argument");
     if (B < 1 || k < 1) return fail(PNGPD_ERR_SHAPE, "pngpd_score: B=%d k=%d", B, k);

@@ -1,0 +1,323 @@
+// Online in-gripper crop (apps/kinect2grasp.py:299-344 check_collision_square, :377-423
+// collect_pc), subsample/pad (:746-774) and the repeat vote (:799-817), for gfx950.
+//
+// The reference runs, per grasp, a float64 numpy pass over the whole scene: normalise the three
+// axes, d = point - centre, pg = R d, six STRICT comparisons, np.where.  To give the same index
+// set bit for bit every kernel here computes in float64 with the same operation order
+//     |v| = sqrt(fma(z,z,fma(y,y,x*x)))        axis = v / |v|
+//     pg[r] = fma(R[r][2], d2, fma(R[r][1], d1, R[r][0]*d0))
+// and contraction of separate multiplies and adds is switched off for this file.
+//
+// Pipeline (all on one stream, no atomics, so the output order is the ascending point index):
+//   frames : normalised frame per grasp                          [G,12] f64 in the workspace
+//   mask   : brute-force box test, one bit per (grasp, point)    [G, Wp] u64 in the workspace
+//            each thread keeps 4 points in registers and walks a block of grasps whose frames
+//            arrive through the scalar cache; wave ballots are staged in LDS and written as
+//            whole 128-byte rows
+//   count  : popcount per grasp, then an exclusive scan over grasps
+//   emit   : per grasp, block-scan of popcounts + bit expansion -> ascending indices
+//   gather : subsample / pad to P points per (grasp, repeat), transform to the gripper frame,
+//            round to float32 = the network input of main_test.py:74-76
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace pngpd {
+
+__global__ void crop_frames_kernel(const double* __restrict__ grasps, double* __restrict__ frames, int G) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const double* in = grasps + (size_t)g * 15;       // [5,3]: row 4 centre, rows 1..3 axes
+    double* f = frames + (size_t)g * 12;
+    f[0] = in[12];
+    f[1] = in[13];
+    f[2] = in[14];
+    for (int r = 0; r < 3; ++r) {
+        const double x = in[3 + 3 * r], y = in[4 + 3 * r], z = in[5 + 3 * r];
+        const double n = sqrt(fma(z, z, fma(y, y, x * x)));
+        f[3 + 3 * r + 0] = x / n;
+        f[3 + 3 * r + 1] = y / n;
+        f[3 + 3 * r + 2] = z / n;
+    }
+}
+
+struct PointD { double x, y, z; };
+
+__device__ __forceinline__ PointD to_gripper(const double* __restrict__ f, double px, double py, double pz) {
+    const double d0 = px - f[0], d1 = py - f[1], d2 = pz - f[2];
+    PointD q;
+    q.x = fma(f[5], d2, fma(f[4], d1, f[3] * d0));
+    q.y = fma(f[8], d2, fma(f[7], d1, f[6] * d0));
+    q.z = fma(f[11], d2, fma(f[10], d1, f[9] * d0));
+    return q;
+}
+
+__device__ __forceinline__ bool in_box(const PointD& q, const CropLimits& L) {
+    return (L.ylo < q.y) & (L.yhi > q.y) & (L.zhi > q.z) & (L.zlo < q.z) & (L.xhi > q.x) & (L.xlo < q.x);
+}
+
+__global__ __launch_bounds__(256) void crop_mask_kernel(const float* __restrict__ scene, int S,
+                                                        const double* __restrict__ frames, int G,
+                                                        CropLimits L, unsigned long long* __restrict__ mask,
+                                                        int Wp) {
+    __shared__ unsigned long long s_mask[CROP_GB][CROP_TILE / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, gb = blockIdx.y;
+    double px[CROP_PPT], py[CROP_PPT], pz[CROP_PPT];
+    bool ok[CROP_PPT];
+#pragma unroll
+    for (int k = 0; k < CROP_PPT; ++k) {
+        const int s = tile * CROP_TILE + k * 256 + tid;
+        ok[k] = s < S;
+        const float* p = scene + (size_t)(ok[k] ? s : 0) * 3;
+        px[k] = (double)p[0];
+        py[k] = (double)p[1];
+        pz[k] = (double)p[2];
+    }
+    const int g_end = min(CROP_GB, G - gb * CROP_GB);
+#pragma unroll 2
+    for (int j = 0; j < g_end; ++j) {
+        const double* f = frames + (size_t)(gb * CROP_GB + j) * 12;   // wave-uniform: scalar loads
+#pragma unroll
+        for (int k = 0; k < CROP_PPT; ++k) {
+            const PointD q = to_gripper(f, px[k], py[k], pz[k]);
+            const unsigned long long bal = __ballot(in_box(q, L) && ok[k]);
+            if (lane == 0) s_mask[j][k * 4 + wave] = bal;
+        }
+    }
+    __syncthreads();
+    constexpr int WPT = CROP_TILE / 64;    // 16 words per (grasp, tile) = one 128-byte row
+    for (int i = tid; i < g_end * WPT; i += 256) {
+        const int j = i / WPT, w = i % WPT;
+        mask[(size_t)(gb * CROP_GB + j) * Wp + (size_t)tile * WPT + w] = s_mask[j][w];
+    }
+}
+
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// Exclusive prefix of v over a 256-thread block and the block total.  s_tmp: 4 ints.
+__device__ __forceinline__ int block_exclusive_scan(int v, int tid, int* s_tmp, int& total) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int inc = wave_inclusive_scan(v, lane);
+    __syncthreads();                       // previous use of s_tmp finished
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    const int t0 = s_tmp[0], t1 = s_tmp[1], t2 = s_tmp[2], t3 = s_tmp[3];
+    total = t0 + t1 + t2 + t3;
+    const int before = wave == 0 ? 0 : wave == 1 ? t0 : wave == 2 ? t0 + t1 : t0 + t1 + t2;
+    return before + inc - v;
+}
+
+__global__ __launch_bounds__(256) void crop_count_kernel(const unsigned long long* __restrict__ mask, int Wp,
+                                                         int* __restrict__ cnt) {
+    __shared__ int s_tmp[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    int c = 0;
+    for (int w = tid; w < Wp; w += 256) c += __popcll(mask[(size_t)g * Wp + w]);
+    int total;
+    block_exclusive_scan(c, tid, s_tmp, total);
+    if (tid == 0) cnt[g] = total;
+}
+
+__global__ __launch_bounds__(256) void crop_offsets_kernel(const int* __restrict__ cnt, int G,
+                                                           long long* __restrict__ offsets) {
+    __shared__ int s_tmp[4];
+    const int tid = threadIdx.x;
+    long long base = 0;
+    for (int g0 = 0; g0 < G; g0 += 256) {
+        const int g = g0 + tid;
+        const int c = g < G ? cnt[g] : 0;
+        int total;
+        const int ex = block_exclusive_scan(c, tid, s_tmp, total);
+        if (g < G) offsets[g] = base + ex;
+        base += total;
+    }
+    if (tid == 0) offsets[G] = base;
+}
+
+__global__ __launch_bounds__(256) void crop_emit_kernel(const unsigned long long* __restrict__ mask, int Wp,
+                                                        const long long* __restrict__ offsets,
+                                                        const float* __restrict__ scene,
+                                                        const double* __restrict__ frames,
+                                                        int* __restrict__ idx, long long capacity,
+                                                        double* __restrict__ pts_g) {
+    __shared__ int s_tmp[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const double* f = frames + (size_t)g * 12;
+    long long base = offsets[g];
+    for (int w0 = 0; w0 < Wp; w0 += 256) {
+        const int w = w0 + tid;
+        unsigned long long word = w < Wp ? mask[(size_t)g * Wp + w] : 0ull;
+        int total;
+        long long o = base + block_exclusive_scan(__popcll(word), tid, s_tmp, total);
+        while (word) {
+            const int b = __ffsll((long long)word) - 1;
+            word &= word - 1;
+            const int s = w * 64 + b;
+            if (o < capacity) {
+                idx[o] = s;
+                if (pts_g != nullptr) {
+                    const float* p = scene + (size_t)s * 3;
+                    const PointD q = to_gripper(f, (double)p[0], (double)p[1], (double)p[2]);
+                    pts_g[3 * o + 0] = q.x;
+                    pts_g[3 * o + 1] = q.y;
+                    pts_g[3 * o + 2] = q.z;
+                }
+            }
+            ++o;
+        }
+        base += total;
+    }
+}
+
+// ---- repo-defined counter-based selection (the reference draws from numpy's global, time-seeded
+// generator, apps/kinect2grasp.py:768-774, which cannot be reproduced) ---------------------------
+__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// i-th draw for (grasp g, repeat r) out of n cropped points, P draws in total.
+// n >= P: i -> a keyed 4-round Feistel permutation of [0, 4^hb) cycle-walked into [0, n): the P
+//         draws are distinct (sampling without replacement);  n < P: independent uniform draws.
+__host__ __device__ __forceinline__ int draw_selection(unsigned long long seed, int g, int r, int i, int n, int P) {
+    const unsigned long long key = mix64(seed ^ mix64((unsigned long long)g * 0x9E3779B97F4A7C15ull + (unsigned long long)r));
+    if (n < P) {
+        const unsigned long long u = mix64(key + (unsigned long long)i) >> 32;
+        return (int)((u * (unsigned long long)n) >> 32);
+    }
+    int hb = 1;
+    while ((1ll << (2 * hb)) < (long long)n) ++hb;
+    const unsigned long long m = (1ull << hb) - 1;
+    unsigned long long x = (unsigned long long)i;
+    do {
+        unsigned long long Lh = x >> hb, Rh = x & m;
+        for (int t = 0; t < 4; ++t) {
+            const unsigned long long F = (mix64(key + ((unsigned long long)(t + 1) << 32) + Rh) >> 20) & m;
+            const unsigned long long nl = Rh;
+            Rh = Lh ^ F;
+            Lh = nl;
+        }
+        x = (Lh << hb) | Rh;
+    } while (x >= (unsigned long long)n);
+    return (int)x;
+}
+
+__global__ __launch_bounds__(256) void crop_gather_kernel(const float* __restrict__ scene,
+                                                          const double* __restrict__ frames,
+                                                          const int* __restrict__ idx,
+                                                          const long long* __restrict__ offsets,
+                                                          const int* __restrict__ cnt, int R, int P,
+                                                          int min_points, const int* __restrict__ sel,
+                                                          unsigned long long seed, float* __restrict__ pts_out,
+                                                          int* __restrict__ sel_out,
+                                                          unsigned char* __restrict__ valid) {
+    const int g = blockIdx.x / R, r = blockIdx.x % R, tid = threadIdx.x;
+    const int n = cnt[g];
+    float* out = pts_out + (size_t)blockIdx.x * P * 3;
+    if (n < min_points) {     // apps/kinect2grasp.py:746-751: scored 0 without running the network
+        for (int i = tid; i < P * 3; i += 256) out[i] = 0.f;
+        if (sel_out != nullptr)
+            for (int i = tid; i < P; i += 256) sel_out[(size_t)blockIdx.x * P + i] = -1;
+        if (r == 0 && tid == 0) valid[g] = 0;
+        return;
+    }
+    if (r == 0 && tid == 0) valid[g] = 1;
+    const double* f = frames + (size_t)g * 12;
+    const long long base = offsets[g];
+    for (int i = tid; i < P; i += 256) {
+        const int j = sel != nullptr ? sel[(size_t)blockIdx.x * P + i] : draw_selection(seed, g, r, i, n, P);
+        if (sel_out != nullptr) sel_out[(size_t)blockIdx.x * P + i] = j;
+        const int s = idx[base + j];
+        const float* p = scene + (size_t)s * 3;
+        const PointD q = to_gripper(f, (double)p[0], (double)p[1], (double)p[2]);
+        out[3 * i + 0] = (float)q.x;
+        out[3 * i + 1] = (float)q.y;
+        out[3 * i + 2] = (float)q.z;
+    }
+}
+
+// One thread per grasp: mode of the R predictions (smallest label among the most frequent, like
+// scipy.stats.mode), mean of probs[:, best] over the agreeing repeats accumulated in float32 in
+// repeat order (numpy's float32 mean of fewer than 8 values), best = 2 for 3 classes else 1.
+__global__ void vote_kernel(const long long* __restrict__ pred, const float* __restrict__ probs,
+                            const unsigned char* __restrict__ valid, int G, int R, int k,
+                            int* __restrict__ label, float* __restrict__ score) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    if (valid != nullptr && !valid[g]) {
+        label[g] = 0;
+        score[g] = 0.f;
+        return;
+    }
+    int best_label = 0, best_count = -1;
+    for (int c = 0; c < k; ++c) {
+        int n = 0;
+        for (int r = 0; r < R; ++r) n += (pred[(size_t)g * R + r] == c);
+        if (n > best_count) { best_count = n; best_label = c; }
+    }
+    const int best = k == 3 ? 2 : 1;
+    float sum = 0.f;
+    for (int r = 0; r < R; ++r)
+        if (pred[(size_t)g * R + r] == best_label) sum += probs[((size_t)g * R + r) * k + best];
+    label[g] = best_label;
+    score[g] = sum / (float)best_count;
+}
+
+int crop_words_per_grasp(int S) {
+    const int tiles = (S + CROP_TILE - 1) / CROP_TILE;
+    return tiles * (CROP_TILE / 64);
+}
+
+hipError_t launch_crop_count(const float* scene, int S, const double* grasps, int G, const CropLimits& L,
+                             double* frames, unsigned long long* mask, int* cnt, long long* offsets,
+                             hipStream_t s) {
+    if (!scene || !grasps || !frames || !mask || !cnt || !offsets || S < 1 || G < 1) return hipErrorInvalidValue;
+    const int Wp = crop_words_per_grasp(S);
+    hipLaunchKernelGGL(crop_frames_kernel, dim3((G + 255) / 256), dim3(256), 0, s, grasps, frames, G);
+    dim3 grid((S + CROP_TILE - 1) / CROP_TILE, (G + CROP_GB - 1) / CROP_GB);
+    hipLaunchKernelGGL(crop_mask_kernel, grid, dim3(256), 0, s, scene, S, frames, G, L, mask, Wp);
+    hipLaunchKernelGGL(crop_count_kernel, dim3(G), dim3(256), 0, s, mask, Wp, cnt);
+    hipLaunchKernelGGL(crop_offsets_kernel, dim3(1), dim3(256), 0, s, cnt, G, offsets);
+    return hipGetLastError();
+}
+
+hipError_t launch_crop_emit(const float* scene, int S, int G, const double* frames,
+                            const unsigned long long* mask, const long long* offsets, int* idx,
+                            long long capacity, double* pts_g, hipStream_t s) {
+    if (!scene || !frames || !mask || !offsets || !idx || S < 1 || G < 1 || capacity < 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(crop_emit_kernel, dim3(G), dim3(256), 0, s, mask, crop_words_per_grasp(S), offsets, scene,
+                       frames, idx, capacity, pts_g);
+    return hipGetLastError();
+}
+
+hipError_t launch_crop_gather(const float* scene, const double* frames, const int* idx, const long long* offsets,
+                              const int* cnt, int G, int R, int P, int min_points, const int* sel,
+                              unsigned long long seed, float* pts_out, int* sel_out, unsigned char* valid,
+                              hipStream_t s) {
+    if (!scene || !frames || !idx || !offsets || !cnt || !pts_out || !valid || G < 1 || R < 1 || P < 1)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(crop_gather_kernel, dim3(G * R), dim3(256), 0, s, scene, frames, idx, offsets, cnt, R, P,
+                       min_points, sel, seed, pts_out, sel_out, valid);
+    return hipGetLastError();
+}
+
+hipError_t launch_vote(const long long* pred, const float* probs, const unsigned char* valid, int G, int R, int k,
+                       int* label, float* score, hipStream_t s) {
+    if (!pred || !probs || !label || !score || G < 1 || R < 1 || k < 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(vote_kernel, dim3((G + 255) / 256), dim3(256), 0, s, pred, probs, valid, G, R, k, label, score);
+    return hipGetLastError();
+}
+
+}  // namespace pngpd

@@ -48,4 +48,26 @@ hipError_t launch_fc_tail(const float* X, const float* W, const float* b, float*
 hipError_t launch_score(const float* logp, int B, int k, float* probs, int64_t* pred,
                         hipStream_t s);
 
+// ---- in-gripper crop -------------------------------------------------------------------------
+constexpr int CROP_PPT = 4;                  // scene points per thread
+constexpr int CROP_TILE = 256 * CROP_PPT;    // scene points per workgroup
+constexpr int CROP_GB = 32;                  // grasps per workgroup
+
+struct CropLimits { double ylo, yhi, zlo, zhi, xlo, xhi; };
+
+int crop_words_per_grasp(int S);             // 64-bit mask words per grasp (tile padded)
+
+hipError_t launch_crop_count(const float* scene, int S, const double* grasps, int G, const CropLimits& L,
+                             double* frames, unsigned long long* mask, int* cnt, long long* offsets,
+                             hipStream_t s);
+hipError_t launch_crop_emit(const float* scene, int S, int G, const double* frames,
+                            const unsigned long long* mask, const long long* offsets, int* idx,
+                            long long capacity, double* pts_g, hipStream_t s);
+hipError_t launch_crop_gather(const float* scene, const double* frames, const int* idx, const long long* offsets,
+                              const int* cnt, int G, int R, int P, int min_points, const int* sel,
+                              unsigned long long seed, float* pts_out, int* sel_out, unsigned char* valid,
+                              hipStream_t s);
+hipError_t launch_vote(const long long* pred, const float* probs, const unsigned char* valid, int G, int R, int k,
+                       int* label, float* score, hipStream_t s);
+
 }  // namespace pngpd

@@ -135,3 +135,31 @@ def candidate_points(seed: int, B: int, P: int, kind: str = "gripper", first: in
     else:
         raise ValueError(f"unknown kind {kind!r}")
     return pts.astype(np.float32)
+
+
+def scene_points(seed: int, S: int, cube: float = 0.5) -> np.ndarray:
+    """Scene cloud float32 [S,3], uniform in [0,cube)^3 (the voxel-centre cloud of the online loop
+    is float32 too, apps/kinect2grasp.py:159)."""
+    return uniform(seed, "scene", (S, 3), 0.0, cube)
+
+
+def random_grasps(seed: int, G: int, cube: float = 0.5, margin: float = 0.06) -> np.ndarray:
+    """Grasp array float64 [G,5,3] in the layout collect_pc reads (apps/kinect2grasp.py:389-396):
+    row 4 = bottom centre, rows 1,2,3 = approach, binormal, minor axis.  Axes form a random
+    right-handed orthogonal frame, each scaled by a random length so that normalisation matters;
+    row 0 (unused by the crop) holds the centre again."""
+    q = normal(seed, "grasp/quat", (G, 4), dtype=np.float64)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([
+        np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+        np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+        np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], 1)   # [G,3,3]
+    lengths = uniform(seed, "grasp/len", (G, 3), 0.5, 2.0, dtype=np.float64)
+    centre = uniform(seed, "grasp/centre", (G, 3), margin, cube - margin, dtype=np.float64)
+    g = np.zeros((G, 5, 3), dtype=np.float64)
+    g[:, 0] = centre
+    g[:, 4] = centre
+    for r in range(3):
+        g[:, 1 + r] = R[:, :, r] * lengths[:, r:r + 1]     # columns of R are the frame axes
+    return g

@@ -1,0 +1,185 @@
+"""GPU parity of the in-gripper crop / subsample / vote path (through the C ABI) against the
+float64 oracle: index sets and gripper-frame coordinates must be BIT-EXACT."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import crop_oracle as co
+from oracle import pointnet_oracle as po
+from pointnetgpd_amd import crop as hc
+from pointnetgpd_amd import synth
+from pointnetgpd_amd.pointnet import PointNetCls
+from pointnetgpd_amd.scoring import score_candidates
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LIMITS = co.box_limits(co.hand_points(hand_depth=0.06, hand_outer_diameter=0.12, finger_width=0.02, hand_height=0.02))
+
+
+def assert_same_crop(res, idx_ref, pts_ref):
+    got_idx = res.index_lists()
+    got_pts = res.point_lists()
+    assert len(got_idx) == len(idx_ref)
+    np.testing.assert_array_equal(res.counts.cpu().numpy(), [len(i) for i in idx_ref])
+    for g, (a, b) in enumerate(zip(got_idx, idx_ref)):
+        assert a.dtype == np.int64
+        np.testing.assert_array_equal(a, b, err_msg=f"grasp {g}")
+    for g, (a, b) in enumerate(zip(got_pts, pts_ref)):
+        assert a.dtype == np.float64
+        np.testing.assert_array_equal(a, b, err_msg=f"grasp {g}: gripper-frame points differ")
+
+
+def test_golden_random_case():
+    d = np.load(os.path.join(GOLDEN, "crop_random.npz"))
+    S, G, seed = (int(v) for v in d["meta"])
+    cube = float(d["cube"])
+    scene, grasps = synth.scene_points(seed, S, cube), synth.random_grasps(seed, G, cube, 0.03)
+    res = hc.collect_pc(grasps, torch.from_numpy(scene).cuda(), d["limits"])
+    np.testing.assert_array_equal(res.counts.cpu().numpy(), d["counts"])
+    np.testing.assert_array_equal(res.indices.cpu().numpy(), d["idx"])
+    n_head = int(d["counts"][:6].sum())
+    np.testing.assert_array_equal(res.points_g.cpu().numpy()[:n_head], d["pts_head"])
+
+
+def test_golden_points_on_planes_are_excluded():
+    d = np.load(os.path.join(GOLDEN, "crop_planes.npz"))
+    res = hc.collect_pc(d["grasps"], torch.from_numpy(d["scene"]).cuda(), d["limits"])
+    np.testing.assert_array_equal(res.counts.cpu().numpy(), d["counts"])
+    np.testing.assert_array_equal(res.indices.cpu().numpy(), d["idx"])
+    np.testing.assert_array_equal(res.points_g.cpu().numpy(), d["pts"])
+
+
+@pytest.mark.parametrize("S,G", [(200_000, 100), (1023, 3), (1025, 33), (50, 1)])
+def test_against_c_oracle(S, G):
+    seed = 61 + G
+    scene, grasps = synth.scene_points(seed, S, 0.3), synth.random_grasps(seed, G, 0.3, 0.03)
+    idx_ref, pts_ref = co.crop_c(grasps, scene, LIMITS)
+    res = hc.collect_pc(grasps.reshape(-1), torch.from_numpy(scene).cuda(), LIMITS)   # flat form as in :385-389
+    assert_same_crop(res, idx_ref, pts_ref)
+
+
+def test_empty_crops():
+    scene = synth.scene_points(5, 5000, 0.1)
+    grasps = synth.random_grasps(5, 4, 0.1, 0.03)
+    grasps[:, 4] += 10.0                     # far away: nothing inside
+    res = hc.collect_pc(grasps, torch.from_numpy(scene).cuda(), LIMITS)
+    assert res.indices.numel() == 0 and int(res.counts.sum()) == 0
+    pts, valid = hc.subsample(res, 750, repeat=3)
+    assert not valid.any() and float(pts.abs().max()) == 0.0
+
+
+def make_crop(S=60_000, G=24, seed=71, cube=0.2):
+    scene, grasps = synth.scene_points(seed, S, cube), synth.random_grasps(seed, G, cube, 0.03)
+    return scene, grasps, hc.collect_pc(grasps, torch.from_numpy(scene).cuda(), LIMITS)
+
+
+def test_subsample_with_given_selection_matches_reference_rule():
+    """points_modify = in_ind_points[ii][np.random.choice(...)] -> FloatTensor (kinect2grasp.py:766-774)."""
+    P, R = 500, 3
+    scene, grasps, res = make_crop()
+    idx_ref, pts_ref = co.crop_c(grasps, scene, LIMITS)
+    rng = np.random.default_rng(0)
+    counts = [len(i) for i in idx_ref]
+    assert min(counts) >= co.MIN_POINTS and any(c < P for c in counts) and any(c >= P for c in counts)
+    sel = np.stack([rng.choice(c, P, replace=c < P) for c in counts for _ in range(R)]).astype(np.int32)
+    pts, valid = hc.subsample(res, P, repeat=R, sel=sel)
+    assert valid.all()
+    expect = np.stack([co.subsample(pts_ref[g], sel[g * R + r]).astype(np.float32) for g in range(len(counts)) for r in range(R)])
+    np.testing.assert_array_equal(pts.cpu().numpy(), expect)
+
+
+def test_device_selection_matches_host_twin_and_sampling_rules():
+    P, R, seed = 500, 3, 1234
+    scene, grasps, res = make_crop()
+    counts = res.counts.cpu().numpy()
+    pts, valid, sel = hc.subsample(res, P, repeat=R, seed=seed, return_selection=True)
+    sel = sel.cpu().numpy()
+    for g, n in enumerate(counts):
+        for r in range(R):
+            row = sel[g * R + r]
+            np.testing.assert_array_equal(row, hc.draw_selection(seed, g, r, int(n), P))
+            assert row.min() >= 0 and row.max() < n
+            if n >= P:
+                assert len(set(row.tolist())) == P          # replace=False
+    assert not np.array_equal(sel[0], sel[1])               # repeats differ
+    # the gathered points are the selected cropped points
+    _, pts_ref = co.crop_c(grasps, scene, LIMITS)
+    np.testing.assert_array_equal(pts[4].cpu().numpy(), pts_ref[1][sel[4]].astype(np.float32))
+
+
+def test_min_points_rule():
+    scene, grasps, res = make_crop(S=3000, G=16, seed=73)      # sparse scene: ~10-20 points per grasp
+    counts = res.counts.cpu().numpy()
+    assert (counts < 20).any() and (counts >= 20).any()
+    pts, valid = hc.subsample(res, 750, repeat=3, seed=1)
+    np.testing.assert_array_equal(valid.cpu().numpy().astype(bool), counts >= 20)
+
+
+def test_vote_matches_reference_rule():
+    rng = np.random.default_rng(3)
+    for k in (2, 3):
+        G, R = 200, 3
+        probs = rng.dirichlet(np.ones(k), size=G * R).astype(np.float32)
+        pred = probs.argmax(1).astype(np.int64)
+        valid = (rng.random(G) > 0.2).astype(np.uint8)
+        label, score = hc.vote(torch.from_numpy(pred).cuda(), torch.from_numpy(probs).cuda(),
+                               torch.from_numpy(valid).cuda(), R)
+        label, score = label.cpu().numpy(), score.cpu().numpy()
+        for g in range(G):
+            if not valid[g]:
+                assert label[g] == 0 and score[g] == 0.0
+                continue
+            l_ref, s_ref = co.vote(pred[g * R:(g + 1) * R], probs[g * R:(g + 1) * R].reshape(R, 1, k), k)
+            assert label[g] == l_ref
+            assert score[g] == np.float32(s_ref), (g, score[g], s_ref)
+
+
+def test_end_to_end_online_scoring_small_scene():
+    """crop -> subsample(given draws) -> network -> softmax/argmax -> vote, against the oracle chain."""
+    P, R, k, seed = 500, 3, 2, 81
+    scene, grasps, res = make_crop(S=80_000, G=12, seed=seed)
+    idx_ref, pts_ref = co.crop_c(grasps, scene, LIMITS)
+    rng = np.random.default_rng(1)
+    counts = [len(i) for i in idx_ref]
+    sel = np.stack([rng.choice(c, P, replace=c < P) for c in counts for _ in range(R)]).astype(np.int32)
+    sd = synth.torch_state_dict(seed, k, 0.02)
+    m = PointNetCls(P, 3, k)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    pts, valid = hc.subsample(res, P, repeat=R, sel=sel)
+    pred, probs, _ = score_candidates(m, pts)
+    label, score = hc.vote(pred, probs, valid, R)
+    oracle = po.build_cls(P, k, sd)
+    for g in range(len(counts)):
+        preds, prs = [], []
+        for r in range(R):
+            p_, pr_ = po.oracle_test_network(oracle, co.subsample(pts_ref[g], sel[g * R + r]))
+            preds.append(int(p_[0]))
+            prs.append(pr_)
+        l_ref, s_ref = co.vote(preds, prs, k)
+        margins = [abs(float(pr[0, 0] - pr[0, 1])) for pr in prs]
+        if min(margins) > 1e-3:
+            assert int(label[g]) == l_ref
+            assert abs(float(score[g]) - float(s_ref)) <= 1e-4
+
+
+def test_full_size_scene_properties():
+    """S = 1,000,000 points x G = 10,000 grasps: ascending indices, counts add up, sampled grasps
+    equal the C oracle bit for bit."""
+    S, G, seed = 1_000_000, 10_000, 91
+    scene, grasps = synth.scene_points(seed, S, 0.5), synth.random_grasps(seed, G, 0.5, 0.06)
+    res = hc.collect_pc(grasps, torch.from_numpy(scene).cuda(), LIMITS, return_points=False)
+    counts, off, idx = res.counts.cpu().numpy(), res.offsets.cpu().numpy(), res.indices.cpu().numpy()
+    assert off[0] == 0 and off[-1] == counts.sum() == idx.size
+    np.testing.assert_array_equal(np.diff(off), counts)
+    assert idx.min() >= 0 and idx.max() < S
+    starts = np.zeros(idx.size, dtype=bool)
+    starts[off[:-1][counts > 0]] = True
+    assert (np.diff(idx.astype(np.int64)) > 0)[~starts[1:]].all()      # ascending inside every grasp
+    assert 600 < counts.mean() < 950
+    pick = [0, 1, 4999, 9999]
+    idx_ref, _ = co.crop_c(grasps[pick], scene, LIMITS)
+    for g, ref in zip(pick, idx_ref):
+        np.testing.assert_array_equal(idx[off[g]:off[g + 1]], ref)

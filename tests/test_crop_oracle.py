@@ -1,0 +1,84 @@
+"""CPU: the crop oracle's three forms (reference numpy calls / pinned fma order / plain C) agree
+bit for bit, match the committed golden vectors, and honour the strict inequalities."""
+import hashlib
+import os
+
+import numpy as np
+
+from oracle import crop_oracle as co
+from pointnetgpd_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def random_case():
+    d = np.load(os.path.join(GOLDEN, "crop_random.npz"))
+    S, G, seed = (int(v) for v in d["meta"])
+    cube = float(d["cube"])
+    return d, synth.scene_points(seed, S, cube), synth.random_grasps(seed, G, cube, 0.03), d["limits"]
+
+
+def test_numpy_form_matches_golden():
+    d, scene, grasps, limits = random_case()
+    idx, pts = co.crop_numpy(grasps, scene, limits)
+    np.testing.assert_array_equal([len(i) for i in idx], d["counts"])
+    np.testing.assert_array_equal(np.concatenate(idx), d["idx"])
+    np.testing.assert_array_equal(np.concatenate(pts[:6]), d["pts_head"])
+    for p, h in zip(pts, d["pts_sha256"]):
+        assert hashlib.sha256(np.ascontiguousarray(p).tobytes()).hexdigest() == str(h)
+
+
+def test_pinned_and_c_forms_are_bit_identical_to_numpy_form():
+    d, scene, grasps, limits = random_case()
+    idx_c, pts_c = co.crop_c(grasps, scene, limits)
+    np.testing.assert_array_equal(np.concatenate(idx_c), d["idx"])
+    np.testing.assert_array_equal(np.concatenate(pts_c[:6]), d["pts_head"])
+    for p, h in zip(pts_c, d["pts_sha256"]):
+        assert hashlib.sha256(np.ascontiguousarray(p).tobytes()).hexdigest() == str(h)
+    centre, a, b, m = co.split_grasps(grasps)
+    for g in (0, 5, 17):
+        i_np, pg_np = co.crop_one_numpy(centre[g], a[g], b[g], m[g], scene, limits)
+        i_pin, pg_pin = co.crop_one_pinned(centre[g], a[g], b[g], m[g], scene, limits)
+        np.testing.assert_array_equal(i_np, i_pin)
+        np.testing.assert_array_equal(pg_np, pg_pin)          # every one of the S x 3 doubles
+        np.testing.assert_array_equal(co.frame_numpy(a[g], b[g], m[g]), co.frame_pinned(a[g], b[g], m[g]))
+
+
+def test_points_on_the_planes_are_excluded():
+    d = np.load(os.path.join(GOLDEN, "crop_planes.npz"))
+    for fn in (co.crop_numpy, co.crop_c):
+        idx, pts = fn(d["grasps"], d["scene"], d["limits"])
+        np.testing.assert_array_equal([len(i) for i in idx], d["counts"])
+        np.testing.assert_array_equal(np.concatenate(idx), d["idx"])
+        np.testing.assert_array_equal(np.concatenate(pts), d["pts"])
+    # frame 0 is the identity: its 19 local points are scene rows 0..18 = centre, then per plane
+    # (on, +1 ulp, -1 ulp).  On-plane points must be out; exactly one neighbour of each is in.
+    idx0 = set(co.crop_numpy(d["grasps"][:1], d["scene"], d["limits"])[0][0].tolist())
+    assert 0 in idx0
+    for plane in range(6):
+        on, up, down = 1 + 3 * plane, 2 + 3 * plane, 3 + 3 * plane
+        assert on not in idx0
+        assert (up in idx0) != (down in idx0)
+
+
+def test_empty_crop_and_grasp_reshape():
+    limits = co.box_limits(co.hand_points(0.06, 0.12, 0.02, 0.02))
+    scene = synth.scene_points(3, 100, 0.1)
+    far = np.zeros((1, 5, 3))
+    far[0, 4] = [5, 5, 5]
+    far[0, 1:4] = np.eye(3)
+    idx, pts = co.crop_numpy(far.reshape(-1), scene, limits)     # flat list form, kinect2grasp.py:389
+    assert len(idx) == 1 and idx[0].size == 0 and pts[0].shape == (0, 3)
+
+
+def test_box_limits_of_hand_model():
+    lim = co.box_limits(co.hand_points(hand_depth=0.06, hand_outer_diameter=0.12, finger_width=0.02, hand_height=0.02))
+    np.testing.assert_allclose(lim, [-0.04, 0.04, -0.01, 0.01, 0.0, 0.06])
+
+
+def test_vote_semantics():
+    probs = np.array([[[0.3, 0.7]], [[0.6, 0.4]], [[0.2, 0.8]]], dtype=np.float32)
+    label, score = co.vote([1, 0, 1], probs, 2)
+    assert label == 1 and score == np.mean(np.array([0.7, 0.8], dtype=np.float32))
+    label, score = co.vote([0, 1, 2], np.ones((3, 1, 3), np.float32) / 3, 3)   # three-way tie -> smallest
+    assert label == 0
