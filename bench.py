@@ -77,6 +77,68 @@ def cpu_baseline(P, k, seed, seconds_budget=15.0):
                       f"torch {torch.__version__} CPU"}
 
 
+def online_workload(args, dev, rank, n_gpus, dist):
+    """Config 5: 1M-point scene x 10k grasps per GPU: crop + subsample (3 repeats) + scoring + vote."""
+    from pointnetgpd_amd import crop as hc
+    from pointnetgpd_amd.online import score_grasps
+
+    S, G, P, k, R = args.scene_points, args.grasps, args.points, args.classes, 3
+    limits = hc.box_limits_from_gripper(synth.GRIPPER_BOX[0], synth.GRIPPER_BOX[1] + 0.04, 0.02, synth.GRIPPER_BOX[2])
+    scene = torch.from_numpy(synth.scene_points(0, S, 0.5)).to(dev)
+    grasps = synth.random_grasps(1000 + rank, G, 0.5, 0.06)
+    model = PointNetCls(P, 3, k)
+    model.load_state_dict(synth.torch_state_dict(0, k, 0.02), strict=True)
+    model = model.to(dev).eval()
+    model.precision = args.precision
+    grasps_dev = torch.from_numpy(grasps).to(dev)
+
+    def step():
+        return score_grasps(model, scene, grasps_dev, limits, repeat=R, seed=0)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # stage split with events on the launch stream
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    res = hc.collect_pc(grasps_dev, scene, limits, return_points=False)
+    e[1].record()
+    pts, valid = hc.subsample(res, P, repeat=R, seed=0)
+    from pointnetgpd_amd.scoring import score_candidates
+    pred, probs, _ = score_candidates(model, pts)
+    hc.vote(pred, probs, valid, R)
+    e[2].record()
+    torch.cuda.synchronize(dev)
+    crop_ms, score_ms = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+    total_idx = int(res.offsets[-1].item())
+    crop_bytes = S * 12 + G * 15 * 8 + G * 4 + total_idx * 4            # algorithmic: scene once, frames, counts, indices
+    if rank == 0:
+        print(json.dumps({
+            "metric": "grasps scored/sec, online crop + scoring", "value": round(n_gpus * G * args.steps / elapsed, 1),
+            "unit": "grasps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 crop + " + args.precision, "data": "synthetic",
+            "config": {"workload": f"scene {S} pts x {G} grasps per GPU, crop+subsample x{R}+PointNetCls P={P}+vote",
+                       "crop_ms": round(crop_ms, 3), "score_ms": round(score_ms, 3), "pair_tests_per_s": round(S * G / (crop_ms * 1e-3), 1),
+                       "crop_algorithmic_GBps": round(crop_bytes / (crop_ms * 1e-3) / 1e9, 2),
+                       "mean_points_per_grasp": round(total_idx / G, 1), "good_grasps": int(out.order.numel())},
+        }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +149,10 @@ def main():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="score", choices=["score", "online"],
+                    help="score: headline batch scoring; online: 1M-point scene x 10k grasps crop+score")
+    ap.add_argument("--scene-points", type=int, default=1_000_000)
+    ap.add_argument("--grasps", type=int, default=10_000)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,6 +170,13 @@ def main():
     n_gpus = world
     if n_gpus != args.gpus and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    if args.workload == "online":
+        online_workload(args, dev, rank, n_gpus, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     B, P, k, seed = args.batch, args.points, args.classes, 0
     model = PointNetCls(P, 3, k)

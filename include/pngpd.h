@@ -157,15 +157,16 @@ int pngpd_crop_emit(const float* scene_dev, int S, int G, const void* workspace_
  * points get valid_dev[g] = 0 and zeros.
  * Selection: sel_dev int32 [G*repeat, P] gives, per output point, the position inside the
  * grasp's index list (what np.random.choice returned in the reference); NULL = draw on the
- * device with the library's counter-based generator keyed by (seed, grasp, repeat, i): without
- * replacement when cnt >= P, with replacement otherwise.  sel_out_dev (optional) receives the
- * positions used.
+ * device with the library's counter-based generator keyed by (seed, first_grasp_id + grasp,
+ * repeat, i): without replacement when cnt >= P, with replacement otherwise (first_grasp_id lets
+ * a rank that holds a slice of the grasps draw what a single GPU would).  sel_out_dev (optional)
+ * receives the positions used.
  */
 int pngpd_crop_gather(const float* scene_dev, int S, int G, const void* workspace_dev,
                       size_t workspace_bytes, const int32_t* idx_dev, const int64_t* offsets_dev,
                       const int32_t* cnt_dev, int repeat, int P, int min_points,
-                      const int32_t* sel_dev, uint64_t seed, float* pts_out_dev,
-                      int32_t* sel_out_dev, uint8_t* valid_dev, void* stream);
+                      const int32_t* sel_dev, uint64_t seed, int first_grasp_id,
+                      float* pts_out_dev, int32_t* sel_out_dev, uint8_t* valid_dev, void* stream);
 
 /*
  * Repeat vote (apps/kinect2grasp.py:799-817): pred_dev int64 [G*repeat], probs_dev [G*repeat,k]

@@ -46,7 +46,7 @@ SIGNATURES = {
     "pngpd_crop_emit": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int64, c_void_p,
                                 c_void_p]),
     "pngpd_crop_gather": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
-                                  c_int, c_int, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                  c_int, c_int, c_void_p, c_uint64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pngpd_vote": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pngpd_score": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }

@@ -91,7 +91,7 @@ def collect_pc(grasp_, pc, limits, return_points=True) -> CropResult:
 
 
 def subsample(crop: CropResult, num_points: int, repeat: int = 3, sel=None, seed: int = 0,
-              min_points: int = MIN_POINTS, return_selection: bool = False):
+              min_points: int = MIN_POINTS, return_selection: bool = False, grasp_offset: int = 0):
     """Network input for every (grasp, repeat): float32 [G*repeat, P, 3] in the gripper frame, plus
     valid uint8 [G] (0 where the grasp has fewer than `min_points` points, :746-751).
 
@@ -114,7 +114,8 @@ def subsample(crop: CropResult, num_points: int, repeat: int = 3, sel=None, seed
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(lib.pngpd_crop_gather(_ptr(crop.scene), S, G, _ptr(crop.workspace), crop.workspace.numel(),
                                          _ptr(idx), _ptr(crop.offsets), _ptr(crop.counts), repeat, num_points,
-                                         min_points, _ptr(sel_t), ctypes.c_uint64(seed & (2 ** 64 - 1)), _ptr(pts),
+                                         min_points, _ptr(sel_t), ctypes.c_uint64(seed & (2 ** 64 - 1)), grasp_offset,
+                                         _ptr(pts),
                                          _ptr(sel_out), _ptr(valid), stream))
     return (pts, valid, sel_out) if return_selection else (pts, valid)
 

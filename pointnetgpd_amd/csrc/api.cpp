@@ -349,8 +349,8 @@ int pngpd_crop_emit(const float* scene_dev, int S, int G, const void* workspace_
 
 int pngpd_crop_gather(const float* scene_dev, int S, int G, const void* workspace_dev, size_t workspace_bytes,
                       const int32_t* idx_dev, const int64_t* offsets_dev, const int32_t* cnt_dev, int repeat,
-                      int P, int min_points, const int32_t* sel_dev, uint64_t seed, float* pts_out_dev,
-                      int32_t* sel_out_dev, uint8_t* valid_dev, void* stream) {
+                      int P, int min_points, const int32_t* sel_dev, uint64_t seed, int first_grasp_id,
+                      float* pts_out_dev, int32_t* sel_out_dev, uint8_t* valid_dev, void* stream) {
     if (!scene_dev || !idx_dev || !offsets_dev || !cnt_dev || !pts_out_dev || !valid_dev)
         return fail(PNGPD_ERR_INVALID, "pngpd_crop_gather: NULL argument");
     if (repeat < 1 || P < 1 || min_points < 1)
@@ -358,7 +358,7 @@ int pngpd_crop_gather(const float* scene_dev, int S, int G, const void* workspac
     int rc = crop_ws_check(S, G, workspace_dev, workspace_bytes);
     if (rc) return rc;
     HIP_TRY(pngpd::launch_crop_gather(scene_dev, (const double*)workspace_dev, idx_dev, (const long long*)offsets_dev,
-                                      cnt_dev, G, repeat, P, min_points, sel_dev, seed, pts_out_dev, sel_out_dev,
+                                      cnt_dev, G, repeat, P, min_points, sel_dev, seed, first_grasp_id, pts_out_dev, sel_out_dev,
                                       valid_dev, (hipStream_t)stream));
     return PNGPD_OK;
 }

@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void crop_gather_kernel(const float* __restric
                                                           const long long* __restrict__ offsets,
                                                           const int* __restrict__ cnt, int R, int P,
                                                           int min_points, const int* __restrict__ sel,
-                                                          unsigned long long seed, float* __restrict__ pts_out,
+                                                          unsigned long long seed, int first_grasp_id,
+                                                          float* __restrict__ pts_out,
                                                           int* __restrict__ sel_out,
                                                           unsigned char* __restrict__ valid) {
     const int g = blockIdx.x / R, r = blockIdx.x % R, tid = threadIdx.x;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void crop_gather_kernel(const float* __restric
     const double* f = frames + (size_t)g * 12;
     const long long base = offsets[g];
     for (int i = tid; i < P; i += 256) {
-        const int j = sel != nullptr ? sel[(size_t)blockIdx.x * P + i] : draw_selection(seed, g, r, i, n, P);
+        const int j = sel != nullptr ? sel[(size_t)blockIdx.x * P + i] : draw_selection(seed, first_grasp_id + g, r, i, n, P);
         if (sel_out != nullptr) sel_out[(size_t)blockIdx.x * P + i] = j;
         const int s = idx[base + j];
         const float* p = scene + (size_t)s * 3;
@@ -304,12 +305,12 @@ hipError_t launch_crop_emit(const float* scene, int S, int G, const double* fram
 
 hipError_t launch_crop_gather(const float* scene, const double* frames, const int* idx, const long long* offsets,
                               const int* cnt, int G, int R, int P, int min_points, const int* sel,
-                              unsigned long long seed, float* pts_out, int* sel_out, unsigned char* valid,
-                              hipStream_t s) {
+                              unsigned long long seed, int first_grasp_id, float* pts_out, int* sel_out,
+                              unsigned char* valid, hipStream_t s) {
     if (!scene || !frames || !idx || !offsets || !cnt || !pts_out || !valid || G < 1 || R < 1 || P < 1)
         return hipErrorInvalidValue;
     hipLaunchKernelGGL(crop_gather_kernel, dim3(G * R), dim3(256), 0, s, scene, frames, idx, offsets, cnt, R, P,
-                       min_points, sel, seed, pts_out, sel_out, valid);
+                       min_points, sel, seed, first_grasp_id, pts_out, sel_out, valid);
     return hipGetLastError();
 }
 

@@ -65,8 +65,8 @@ hipError_t launch_crop_emit(const float* scene, int S, int G, const double* fram
                             long long capacity, double* pts_g, hipStream_t s);
 hipError_t launch_crop_gather(const float* scene, const double* frames, const int* idx, const long long* offsets,
                               const int* cnt, int G, int R, int P, int min_points, const int* sel,
-                              unsigned long long seed, float* pts_out, int* sel_out, unsigned char* valid,
-                              hipStream_t s);
+                              unsigned long long seed, int first_grasp_id, float* pts_out, int* sel_out,
+                              unsigned char* valid, hipStream_t s);
 hipError_t launch_vote(const long long* pred, const float* probs, const unsigned char* valid, int G, int R, int k,
                        int* label, float* score, hipStream_t s);
 

@@ -183,3 +183,27 @@ def test_full_size_scene_properties():
     idx_ref, _ = co.crop_c(grasps[pick], scene, LIMITS)
     for g, ref in zip(pick, idx_ref):
         np.testing.assert_array_equal(idx[off[g]:off[g + 1]], ref)
+
+
+def test_online_pipeline_ranks_good_grasps():
+    from pointnetgpd_amd.dist import score_grasps_sharded
+    from pointnetgpd_amd.online import score_grasps
+    P, k, seed = 500, 2, 83
+    scene = torch.from_numpy(synth.scene_points(seed, 80_000, 0.2)).cuda()
+    grasps = synth.random_grasps(seed, 40, 0.2, 0.03)
+    m = PointNetCls(P, 3, k)
+    m.load_state_dict(synth.torch_state_dict(seed, k, 0.02))
+    m = m.cuda().eval()
+    out = score_grasps(m, scene, grasps, LIMITS, repeat=3, seed=5)
+    label, score, valid = score_grasps_sharded(m, scene, grasps, LIMITS, repeat=3, seed=5)
+    assert torch.equal(out.label, label) and torch.equal(out.score, score) and torch.equal(out.valid, valid)
+    s = out.score[out.order].cpu().numpy()
+    assert (np.diff(s) <= 0).all()
+    assert set(out.order.cpu().tolist()) == set(np.nonzero((out.label.cpu().numpy() == 1) & (out.valid.cpu().numpy() != 0))[0].tolist())
+    # a slice scored with its global offset draws what the full run drew
+    from pointnetgpd_amd import crop as hc2
+    res = hc2.collect_pc(grasps[10:20], scene, LIMITS, return_points=False)
+    pts_slice, _ = hc2.subsample(res, P, repeat=3, seed=5, grasp_offset=10)
+    res_all = hc2.collect_pc(grasps, scene, LIMITS, return_points=False)
+    pts_all, _ = hc2.subsample(res_all, P, repeat=3, seed=5)
+    assert torch.equal(pts_slice, pts_all[30:60])
