@@ -176,6 +176,46 @@ int pngpd_crop_gather(const float* scene_dev, int S, int G, const void* workspac
 int pngpd_vote(const int64_t* pred_dev, const float* probs_dev, const uint8_t* valid_dev, int G,
                int repeat, int k, int32_t* label_dev, float* score_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training step: main_1v.py:262-274 (model.train(); output,_ = model(data); nll_loss; backward;
+ * Adam).  fp32 throughout, train-mode BatchNorm1d with torch defaults (batch statistics, biased
+ * variance for normalisation, running stats updated with momentum 0.1 and the unbiased variance,
+ * eps 1e-5), max-pool gradient to the first arg-max.
+ *
+ * params_dev / grads_dev: PNGPD_SLOTS DEVICE pointers laid out like the weight table of
+ * pngpd_model_load (weight, bias, bn_weight, bn_bias, bn_mean = running_mean, bn_var =
+ * running_var); all 12 units are required.  Forward updates the running statistics in place;
+ * backward writes gradients for weight / bias / bn_weight / bn_bias (the bn_mean / bn_var slots of
+ * grads_dev are ignored).  The bias of a layer followed by BatchNorm gets an exact 0.
+ * The workspace carries the saved activations from forward to backward: same B, P, k, same
+ * buffer, nothing else may write it in between.  B >= 2 (main_1v.py:258 skips smaller batches).
+ * ------------------------------------------------------------------------------------------ */
+size_t pngpd_train_workspace_bytes(int B, int P, int k);
+
+/* x_dev float32 [B,3,P] -> logp_dev [B,k], trans_dev [B,3,3] (optional), feat_dev [B,1024] (optional). */
+int pngpd_train_forward(int B, int P, int k, const float* x_dev, float* const* params_dev,
+                        int n_slots, float momentum, float* logp_dev, float* trans_dev,
+                        float* feat_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* dlogp_dev [B,k]: gradient of the loss w.r.t. the log-probabilities; dtrans_dev [B,3,3] optional
+ * gradient w.r.t. the returned transform (the reference discards it, main_1v.py:268). */
+int pngpd_train_backward(int B, int P, int k, const float* x_dev, const float* const* params_dev,
+                         float* const* grads_dev, int n_slots, const float* logp_dev,
+                         const float* dlogp_dev, const float* dtrans_dev, void* workspace_dev,
+                         size_t workspace_bytes, void* stream);
+
+/* F.nll_loss(logp, target) with mean reduction (main_1v.py:270): loss_dev[1] and its gradient
+ * dlogp_dev [B,k].  target_dev int64 [B]. */
+int pngpd_nll_loss(const float* logp_dev, const int64_t* target_dev, int B, int k, float* loss_dev,
+                   float* dlogp_dev, void* stream);
+
+/* One torch.optim.Adam step (no weight decay, no amsgrad; main_1v.py:226) over flat buffers of n
+ * floats; `step` counts from 1; gradients are multiplied by grad_scale first (1/world_size after
+ * a sum all-reduce). */
+int pngpd_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev,
+                    float* exp_avg_sq_dev, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int step, float grad_scale, void* stream);
+
 /*
  * Diagnostic: time the fused conv-stack kernel alone.  Launches the STN stack (which = 0) or the
  * trunk stack (which = 1; uses an identity transform) `iters` times on `stream` between two HIP

@@ -48,6 +48,14 @@ SIGNATURES = {
     "pngpd_crop_gather": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_void_p, c_uint64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pngpd_vote": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pngpd_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pngpd_train_forward": (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p), c_int, c_float, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pngpd_train_backward": (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pngpd_nll_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pngpd_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                                c_int, c_float, c_void_p]),
     "pngpd_score": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 

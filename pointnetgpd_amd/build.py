@@ -26,6 +26,7 @@ LIB_SOURCES = [
     "fc.hip",
     "crop.hip",
     "train.hip",
+    "train_api.cpp",
 ]
 
 

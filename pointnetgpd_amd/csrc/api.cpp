@@ -7,14 +7,16 @@
 #include <string>
 #include <vector>
 
+#include "api_common.h"
 #include "kernels.h"
 #include "pack.h"
 #include "pngpd.h"
 
 namespace {
-
 thread_local std::string g_last_error;
+}
 
+namespace pngpd {
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -24,14 +26,11 @@ int fail(int code, const char* fmt, ...) {
     g_last_error = buf;
     return code;
 }
+}  // namespace pngpd
 
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(PNGPD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                                  \
-    } while (0)
+namespace {
+
+using pngpd::fail;
 
 struct DevBuf {
     void* p = nullptr;

@@ -70,4 +70,39 @@ hipError_t launch_crop_gather(const float* scene, const double* frames, const in
 hipError_t launch_vote(const long long* pred, const float* probs, const unsigned char* valid, int G, int R, int k,
                        int* label, float* score, hipStream_t s);
 
+// ---- training step (train.hip) ---------------------------------------------------------------
+constexpr int TN_ROWS_PER_CHUNK = 2048;      // rows of one weight-gradient partial (multiple of 32)
+
+int t_red_blocks(int M);                     // row blocks of the column reductions
+int t_tn_chunks(int M);                      // partials of a weight-gradient product
+
+hipError_t t_points_to_rows(const float* x, const float* trans, float* X3, int B, int P, hipStream_t s);
+hipError_t t_conv1_fwd(const float* X3, const float* W1, const float* b1, float* y1, int M, hipStream_t s);
+hipError_t t_bn_stats(const float* A, int M, int C, float momentum, double* part, float* mean, float* rstd,
+                      float* running_mean, float* running_var, hipStream_t s);
+hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        float* h, int M, int C, int relu, hipStream_t s);
+hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean, const float* rstd,
+                    const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
+                    float* dbeta, hipStream_t s);
+hipError_t t_maxpool_bn(const float* y3, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        int B, int P, int C, int relu, float* pooled, int* arg, hipStream_t s);
+hipError_t t_pool_bwd(float* y3, const float* dpooled, const float* pooled, const int* arg, const float* mean,
+                      const float* rstd, const float* gamma, int B, int P, int C, int relu, float* m1, float* m2,
+                      float* dgamma, float* dbeta, hipStream_t s);
+hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s);
+hipError_t t_gemm_tn(const float* dY, const float* Hm, float* part, float* dW, int M, int N, int K, hipStream_t s);
+hipError_t t_conv1_bwd(const float* dy1, const float* X3, const float* W1, int M, double* part, float* dW1,
+                       float* dX3, hipStream_t s);
+hipError_t t_trans_grad(const float* x, const float* dX3, int B, int P, const float* dtrans_ext, float* dtrans,
+                        hipStream_t s);
+hipError_t t_small_bwd(const float* dZ, const float* A, const float* W, float* dA, float* dW, float* db, int M, int N,
+                       int K, hipStream_t s);
+hipError_t t_fill(float* p, size_t n, float v, hipStream_t s);
+hipError_t t_logsoftmax_bwd(const float* logp, const float* dlogp, float* dlogits, int B, int k, hipStream_t s);
+hipError_t t_nll_loss(const float* logp, const long long* target, int B, int k, float* loss, float* dlogp,
+                      hipStream_t s);
+hipError_t t_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                  int step, float grad_scale, hipStream_t s);
+
 }  // namespace pngpd

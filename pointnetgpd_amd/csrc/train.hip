@@ -1,0 +1,644 @@
+// Training step kernels (train-mode BatchNorm, backward, Adam) for the path of
+// main_1v.py:262-274: output = model(data); nll_loss; backward; Adam(lr, betas .9/.999, eps 1e-8).
+//
+// Layout: activations are "rows" matrices [M, C] float32, M = B*P rows ordered (candidate, point)
+// for the per-point layers and M = B for the fully connected layers.  All matrix products run on
+// the exact-f32 MFMA (v_mfma_f32_32x32x2_f32) in three shapes:
+//     NT  Y[M,N]  = X[M,K]  W[N,K]^T + b      forward            (fc_f32_kernel in fc.hip)
+//     NN  dX[M,K] = dY[M,N] W[N,K]            input gradient     (gemm_nn_kernel)
+//     TN  dW[N,K] = dY[M,N]^T H[M,K]          weight gradient    (gemm_tn_kernel, split over M)
+// BatchNorm uses batch statistics over the M rows (biased variance for the normalisation,
+// unbiased for running_var, momentum 0.1, eps 1e-5: torch.nn.BatchNorm1d defaults, which the
+// reference keeps, model/pointnet.py:21-25).  Its backward is
+//     dy = gamma*rstd*(g - mean(g) - yhat*mean(g*yhat)),   g = dh*(h > 0)
+// For the 1024-channel layer g is sparse (only the arg-max row of each (candidate, channel)
+// receives gradient from the max-pool), so the two means come from B*1024 values and the dense
+// part of dy is written in place over y.  The bias of a layer that feeds a BatchNorm has an
+// exactly zero gradient (sum_m dy = 0) and is written as 0.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace pngpd {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr float BN_EPS = 1e-5f;
+
+// ---------------------------------------------------------------------------------------------
+// points -> rows, first layer
+// ---------------------------------------------------------------------------------------------
+// X3[m, c] = sum_j x[b, j, p] * T[b, j, c]   (T = identity when trans == nullptr); m = b*P + p
+__global__ void k_points_to_rows(const float* __restrict__ x, const float* __restrict__ trans,
+                                 float* __restrict__ X3, int B, int P) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= B * P) return;
+    const int b = m / P, p = m - b * P;
+    const float* xb = x + (size_t)b * 3 * P;
+    const float x0 = xb[p], x1 = xb[P + p], x2 = xb[2 * P + p];
+    float o0 = x0, o1 = x1, o2 = x2;
+    if (trans != nullptr) {
+        const float* T = trans + (size_t)b * 9;
+        o0 = x0 * T[0] + x1 * T[3] + x2 * T[6];
+        o1 = x0 * T[1] + x1 * T[4] + x2 * T[7];
+        o2 = x0 * T[2] + x1 * T[5] + x2 * T[8];
+    }
+    X3[(size_t)m * 3 + 0] = o0;
+    X3[(size_t)m * 3 + 1] = o1;
+    X3[(size_t)m * 3 + 2] = o2;
+}
+
+// y1[m, c] = W1[c,:] . X3[m,:] + b1[c], 64 channels; 4 rows per 256-thread block
+__global__ void k_conv1_fwd(const float* __restrict__ X3, const float* __restrict__ W1,
+                            const float* __restrict__ b1, float* __restrict__ y1, int M) {
+    const int c = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* xr = X3 + (size_t)m * 3;
+    y1[(size_t)m * 64 + c] = W1[3 * c] * xr[0] + W1[3 * c + 1] * xr[1] + W1[3 * c + 2] * xr[2] + b1[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// column reductions over the rows of [M, C] matrices (two-stage, double accumulation of partials)
+//   mode 0 (statistics): s1 = sum(a - a0), s2 = sum((a - a0)^2), a0 = A[0][c] (shift against cancellation)
+//   mode 1 (bn backward): s1 = sum(g), s2 = sum(g*yhat); g = A*(H > 0) (H optional), yhat = (Y-mean)*rstd
+// part: [nblk][2][C] doubles
+// ---------------------------------------------------------------------------------------------
+constexpr int RED_ROWS = 256;   // rows per block
+
+__global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ A, const float* __restrict__ H,
+                                                   const float* __restrict__ Y, const float* __restrict__ mean,
+                                                   const float* __restrict__ rstd, int M, int C, int mode,
+                                                   double* __restrict__ part) {
+    // block = 256 threads = 64 columns x 4 row lanes; grid = (ceil(C/64), ceil(M/RED_ROWS))
+    __shared__ double s1s[4][64], s2s[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * RED_ROWS;
+    const int r1 = min(M, r0 + RED_ROWS);
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        if (mode == 0) {
+            const float a0 = A[c];
+            for (int r = r0 + rl; r < r1; r += 4) {
+                const float d = A[(size_t)r * C + c] - a0;
+                s1 += d;
+                s2 += d * d;
+            }
+        } else {
+            const float mu = mean[c], rs = rstd[c];
+            for (int r = r0 + rl; r < r1; r += 4) {
+                float g = A[(size_t)r * C + c];
+                if (H != nullptr && !(H[(size_t)r * C + c] > 0.f)) g = 0.f;
+                s1 += g;
+                s2 += g * ((Y[(size_t)r * C + c] - mu) * rs);
+            }
+        }
+    }
+    s1s[rl][cl] = (double)s1;
+    s2s[rl][cl] = (double)s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const double a = s1s[0][cl] + s1s[1][cl] + s1s[2][cl] + s1s[3][cl];
+        const double b = s2s[0][cl] + s2s[1][cl] + s2s[2][cl] + s2s[3][cl];
+        part[((size_t)blockIdx.y * 2 + 0) * C + c] = a;
+        part[((size_t)blockIdx.y * 2 + 1) * C + c] = b;
+    }
+}
+
+// Finalise batch statistics: mean, rstd; update running stats (momentum, unbiased variance).
+__global__ void k_stats_finalize(const double* __restrict__ part, int nblk, const float* __restrict__ A, int M,
+                                 int C, float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                 float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nblk; ++i) {
+        s1 += part[((size_t)i * 2 + 0) * C + c];
+        s2 += part[((size_t)i * 2 + 1) * C + c];
+    }
+    const double dm = s1 / M;                      // mean of the shifted data
+    const double mu = (double)A[c] + dm;
+    double var = s2 / M - dm * dm;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+    if (running_mean != nullptr) {
+        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
+// m1 = s1/M, m2 = s2/M; dgamma = s2, dbeta = s1
+__global__ void k_bnbwd_finalize(const double* __restrict__ part, int nblk, int M, int C, float* __restrict__ m1,
+                                 float* __restrict__ m2, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nblk; ++i) {
+        s1 += part[((size_t)i * 2 + 0) * C + c];
+        s2 += part[((size_t)i * 2 + 1) * C + c];
+    }
+    m1[c] = (float)(s1 / M);
+    m2[c] = (float)(s2 / M);
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+}
+
+// h = relu((y - mean)*rstd*gamma + beta)   (relu optional)
+__global__ void k_bn_act_fwd(const float* __restrict__ y, const float* __restrict__ mean,
+                             const float* __restrict__ rstd, const float* __restrict__ gamma,
+                             const float* __restrict__ beta, float* __restrict__ h, size_t n, int C, int relu) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    float v = (y[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+    if (relu) v = fmaxf(v, 0.f);
+    h[i] = v;
+}
+
+// dense BN backward, in place over dh:  dh <- gamma*rstd*(g - m1 - yhat*m2), g = dh*(h>0)
+__global__ void k_bn_bwd_dense(float* __restrict__ dh, const float* __restrict__ h, const float* __restrict__ y,
+                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                               const float* __restrict__ gamma, const float* __restrict__ m1,
+                               const float* __restrict__ m2, size_t n, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    float g = dh[i];
+    if (h != nullptr && !(h[i] > 0.f)) g = 0.f;
+    const float yh = (y[i] - mean[c]) * rstd[c];
+    dh[i] = gamma[c] * rstd[c] * (g - m1[c] - yh * m2[c]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// max-pool over the points of each candidate with BN (+ optional ReLU) applied on the fly
+// pooled[b,c] = max_p act(bn(y3[b,p,c])), arg = first p attaining it (torch max_pool1d rule)
+// block: 256 threads = 64 channels x 4 point lanes; grid (C/64, B)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_maxpool_bn(const float* __restrict__ y3, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int P, int C, int relu,
+                                                    float* __restrict__ pooled, int* __restrict__ arg) {
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    const float sc = rstd[c] * gamma[c], mu = mean[c], be = beta[c];
+    float best = -INFINITY;
+    int bi = 0;
+    for (int p = pl; p < P; p += 4) {
+        const float v = (y3[((size_t)b * P + p) * C + c] - mu) * sc + be;
+        if (v > best) { best = v; bi = p; }
+    }
+    sv[pl][cl] = best;
+    si[pl][cl] = bi;
+    __syncthreads();
+    if (pl == 0) {
+        for (int k = 1; k < 4; ++k) {
+            const float v = sv[k][cl];
+            const int i = si[k][cl];
+            if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+        }
+        pooled[(size_t)b * C + c] = relu ? fmaxf(best, 0.f) : best;
+        arg[(size_t)b * C + c] = bi;
+    }
+}
+
+// sparse BN-backward reductions for the pooled layer: one thread per channel, loop over candidates
+//   g = dpooled[b,c] * (relu ? pooled[b,c] > 0 : 1); yhat at the arg row
+__global__ void k_pool_bwd_reduce(const float* __restrict__ dpooled, const float* __restrict__ pooled,
+                                  const int* __restrict__ arg, const float* __restrict__ y3,
+                                  const float* __restrict__ mean, const float* __restrict__ rstd, int B, int P, int C,
+                                  int relu, float* __restrict__ m1, float* __restrict__ m2,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    const float mu = mean[c], rs = rstd[c];
+    for (int b = 0; b < B; ++b) {
+        float g = dpooled[(size_t)b * C + c];
+        if (relu && !(pooled[(size_t)b * C + c] > 0.f)) g = 0.f;
+        const float yh = (y3[((size_t)b * P + arg[(size_t)b * C + c]) * C + c] - mu) * rs;
+        s1 += (double)g;
+        s2 += (double)(g * yh);
+    }
+    const double M = (double)B * P;
+    m1[c] = (float)(s1 / M);
+    m2[c] = (float)(s2 / M);
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+}
+
+// dense part, in place: y3 <- -gamma*rstd*(m1 + yhat*m2)
+__global__ void k_pool_bwd_dense(float* __restrict__ y3, const float* __restrict__ mean,
+                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                 const float* __restrict__ m1, const float* __restrict__ m2, size_t n, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const float yh = (y3[i] - mean[c]) * rstd[c];
+    y3[i] = -gamma[c] * rstd[c] * (m1[c] + yh * m2[c]);
+}
+
+// sparse part: dy3[arg row, c] += gamma*rstd*g      (one distinct element per (b,c): no atomics)
+__global__ void k_pool_bwd_sparse(float* __restrict__ dy3, const float* __restrict__ dpooled,
+                                  const float* __restrict__ pooled, const int* __restrict__ arg,
+                                  const float* __restrict__ rstd, const float* __restrict__ gamma, int B, int P,
+                                  int C, int relu) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * C) return;
+    const int c = (int)(i % C);
+    const size_t b = i / C;
+    float g = dpooled[i];
+    if (relu && !(pooled[i] > 0.f)) g = 0.f;
+    dy3[(b * P + arg[i]) * C + c] += gamma[c] * rstd[c] * g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact-f32 MFMA GEMMs for the backward pass
+// ---------------------------------------------------------------------------------------------
+constexpr int GB_M = 64, GB_N = 64, GB_K = 32;
+
+// dX[M,Kout] = dY[M,N] W[N,Kout];  Kout % 64 == 0, N % 32 == 0.
+// optional fused mask: dX *= (Hmask > 0) is NOT applied here (BN backward needs the unmasked sums).
+__global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ dY, const float* __restrict__ W,
+                                                      float* __restrict__ dX, int M, int N, int Kout) {
+    __shared__ float sA[GB_M * (GB_K + 1)];
+    __shared__ float sB[GB_K * GB_N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GB_M, k0 = blockIdx.x * GB_N;
+    const int arow = tid >> 3, acol = (tid & 7) * 4;        // A tile 64x32: 2 float4 per thread
+    const int brow = tid >> 4, bcol = (tid & 15) * 4;       // B tile 32x64: 2 float4 per thread
+    f32x16 acc = {0};
+    for (int n0 = 0; n0 < N; n0 += GB_K) {
+        float4 va[2], vb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gm = m0 + arow + 32 * i;
+            va[i] = gm < M ? *(const float4*)(dY + (size_t)gm * N + n0 + acol) : make_float4(0, 0, 0, 0);
+            vb[i] = *(const float4*)(W + (size_t)(n0 + brow + 16 * i) * Kout + k0 + bcol);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float* pa = sA + (arow + 32 * i) * (GB_K + 1) + acol;
+            pa[0] = va[i].x; pa[1] = va[i].y; pa[2] = va[i].z; pa[3] = va[i].w;
+            *(float4*)(sB + (brow + 16 * i) * GB_N + bcol) = vb[i];
+        }
+        __syncthreads();
+        const float* ra = sA + (wm * 32 + r) * (GB_K + 1) + h;
+        const float* rb = sB + h * GB_N + wn * 32 + r;
+#pragma unroll
+        for (int s = 0; s < GB_K / 2; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[2 * s], rb[2 * s * GB_N], acc, 0, 0, 0);
+    }
+    const int col = k0 + wn * 32 + r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (row < M) dX[(size_t)row * Kout + col] = acc[i];
+    }
+}
+
+// partial dW[chunk][N,K] = dY[rows of chunk, N]^T H[rows of chunk, K];  N % 64 == 0, K % 64 == 0
+// grid (K/64, N/64, chunks); rows_per_chunk % 32 == 0
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dY, const float* __restrict__ Hm,
+                                                      float* __restrict__ part, int M, int N, int K,
+                                                      int rows_per_chunk) {
+    __shared__ float sA[GB_K * GB_M];   // [m][n] 32 x 64
+    __shared__ float sB[GB_K * GB_N];   // [m][k] 32 x 64
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int row_begin = blockIdx.z * rows_per_chunk;
+    const int row_end = min(M, row_begin + rows_per_chunk);
+    const int lrow = tid >> 4, lcol = (tid & 15) * 4;        // 32x64 tile: 2 float4 per thread
+    f32x16 acc = {0};
+    for (int mb = row_begin; mb < row_end; mb += GB_K) {
+        float4 va[2], vb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gm = mb + lrow + 16 * i;
+            const bool ok = gm < row_end;
+            va[i] = ok ? *(const float4*)(dY + (size_t)gm * N + n0 + lcol) : make_float4(0, 0, 0, 0);
+            vb[i] = ok ? *(const float4*)(Hm + (size_t)gm * K + k0 + lcol) : make_float4(0, 0, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(float4*)(sA + (lrow + 16 * i) * GB_M + lcol) = va[i];
+            *(float4*)(sB + (lrow + 16 * i) * GB_N + lcol) = vb[i];
+        }
+        __syncthreads();
+        const float* ra = sA + h * GB_M + wm * 32 + r;      // A[i = n][kk = m]
+        const float* rb = sB + h * GB_N + wn * 32 + r;      // B[kk = m][j = k]
+#pragma unroll
+        for (int s = 0; s < GB_K / 2; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[2 * s * GB_M], rb[2 * s * GB_N], acc, 0, 0, 0);
+    }
+    float* out = part + (size_t)blockIdx.z * N * K;
+    const int col = k0 + wn * 32 + r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = n0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        out[(size_t)row * K + col] = acc[i];
+    }
+}
+
+// out[i] = sum over chunks of part[chunk][i]  (fixed order: reproducible)
+__global__ void k_reduce_chunks(const float* __restrict__ part, int chunks, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * n + i];
+    out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small layers: conv1 backward, the two 256 -> {9,k} layers, 3x3 transform gradient, loss
+// ---------------------------------------------------------------------------------------------
+// partial sums of dW1[c,j] = sum_m dy1[m,c]*X3[m,j] over RED_ROWS rows; part [nblk][64*3] doubles
+__global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ dy1, const float* __restrict__ X3,
+                                                     int M, double* __restrict__ part) {
+    __shared__ double sp[4][64][3];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * RED_ROWS, r1 = min(M, r0 + RED_ROWS);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int r = r0 + rl; r < r1; r += 4) {
+        const float g = dy1[(size_t)r * 64 + cl];
+        s0 += g * X3[(size_t)r * 3 + 0];
+        s1 += g * X3[(size_t)r * 3 + 1];
+        s2 += g * X3[(size_t)r * 3 + 2];
+    }
+    sp[rl][cl][0] = s0; sp[rl][cl][1] = s1; sp[rl][cl][2] = s2;
+    __syncthreads();
+    if (rl == 0)
+        for (int j = 0; j < 3; ++j)
+            part[(size_t)blockIdx.x * 192 + cl * 3 + j] = sp[0][cl][j] + sp[1][cl][j] + sp[2][cl][j] + sp[3][cl][j];
+}
+
+__global__ void k_reduce_double(const double* __restrict__ part, int nblk, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + i];
+    out[i] = (float)s;
+}
+
+// dX3[m, j] = sum_c dy1[m,c] * W1[c,j]      (one wave per row)
+__global__ __launch_bounds__(256) void k_conv1_dgrad(const float* __restrict__ dy1, const float* __restrict__ W1,
+                                                     float* __restrict__ dX3, int M) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float g = dy1[(size_t)m * 64 + lane];
+    float a0 = g * W1[3 * lane], a1 = g * W1[3 * lane + 1], a2 = g * W1[3 * lane + 2];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a0 += __shfl_xor(a0, off);
+        a1 += __shfl_xor(a1, off);
+        a2 += __shfl_xor(a2, off);
+    }
+    if (lane == 0) {
+        dX3[(size_t)m * 3 + 0] = a0;
+        dX3[(size_t)m * 3 + 1] = a1;
+        dX3[(size_t)m * 3 + 2] = a2;
+    }
+}
+
+// dtrans[b, j, c] (+)= sum_p x[b, j, p] * dX3[b*P + p, c]     (one block per candidate)
+__global__ __launch_bounds__(256) void k_trans_grad(const float* __restrict__ x, const float* __restrict__ dX3,
+                                                    int P, const float* __restrict__ dtrans_ext,
+                                                    float* __restrict__ dtrans) {
+    __shared__ float sp[4][9];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float a[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = 0.f;
+    const float* xb = x + (size_t)b * 3 * P;
+    for (int p = tid; p < P; p += 256) {
+        const float* d = dX3 + ((size_t)b * P + p) * 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float xv = xb[j * P + p];
+            a[3 * j + 0] += xv * d[0];
+            a[3 * j + 1] += xv * d[1];
+            a[3 * j + 2] += xv * d[2];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a[i] += __shfl_xor(a[i], off);
+        if (lane == 0) sp[wave][i] = a[i];
+    }
+    __syncthreads();
+    if (tid < 9) {
+        float v = sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid];
+        if (dtrans_ext != nullptr) v += dtrans_ext[(size_t)b * 9 + tid];
+        dtrans[(size_t)b * 9 + tid] = v;
+    }
+}
+
+// tiny-output layer backward (N <= 16, K = 256):  dA[m,k] = sum_n dZ[m,n] W[n,k]
+__global__ void k_small_dgrad(const float* __restrict__ dZ, const float* __restrict__ W, float* __restrict__ dA,
+                              int M, int N, int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * K) return;
+    const int k = (int)(i % K);
+    const size_t m = i / K;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dZ[m * N + n] * W[(size_t)n * K + k];
+    dA[i] = s;
+}
+
+// dW[n,k] = sum_m dZ[m,n] A[m,k];  db[n] = sum_m dZ[m,n]     (thread per (n,k); M = batch)
+__global__ void k_small_wgrad(const float* __restrict__ dZ, const float* __restrict__ A, float* __restrict__ dW,
+                              float* __restrict__ db, int M, int N, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * K) return;
+    const int k = i % K, n = i / K;
+    float s = 0.f, sb = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float g = dZ[(size_t)m * N + n];
+        s += g * A[(size_t)m * K + k];
+        sb += g;
+    }
+    dW[i] = s;
+    if (k == 0) db[n] = sb;
+}
+
+// db[n] = sum_m dY[m,n] for layers WITHOUT a following BatchNorm is handled by k_small_wgrad;
+// zero-fill for layers that feed a BatchNorm.
+__global__ void k_fill(float* __restrict__ p, size_t n, float v) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// grad of log_softmax: dlogits = dlogp - softmax * sum_j dlogp_j  (logp are log-probabilities)
+__global__ void k_logsoftmax_bwd(const float* __restrict__ logp, const float* __restrict__ dlogp,
+                                 float* __restrict__ dlogits, int B, int k) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) s += dlogp[(size_t)b * k + j];
+    for (int j = 0; j < k; ++j) dlogits[(size_t)b * k + j] = dlogp[(size_t)b * k + j] - expf(logp[(size_t)b * k + j]) * s;
+}
+
+// F.nll_loss(logp, target) with mean reduction and its gradient wrt logp (main_1v.py:270)
+__global__ void k_nll_loss(const float* __restrict__ logp, const long long* __restrict__ target, int B, int k,
+                           float* __restrict__ loss, float* __restrict__ dlogp) {
+    __shared__ float s[256];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const int t = (int)target[b];
+        acc -= logp[(size_t)b * k + t];
+        for (int j = 0; j < k; ++j) dlogp[(size_t)b * k + j] = (j == t) ? -1.0f / B : 0.f;
+    }
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = s[0] / B;
+}
+
+// torch.optim.Adam defaults (no amsgrad, no weight decay): one fused pass over the flat buffers.
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, size_t n, float step_size, float b1, float b2, float eps,
+                       float bc2_sqrt, float grad_scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * grad_scale;
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);                  // lerp form used by torch
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= step_size * (mi / denom);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------
+static inline dim3 grid1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+hipError_t t_points_to_rows(const float* x, const float* trans, float* X3, int B, int P, hipStream_t s) {
+    hipLaunchKernelGGL(k_points_to_rows, grid1((size_t)B * P), dim3(256), 0, s, x, trans, X3, B, P);
+    return hipGetLastError();
+}
+hipError_t t_conv1_fwd(const float* X3, const float* W1, const float* b1, float* y1, int M, hipStream_t s) {
+    hipLaunchKernelGGL(k_conv1_fwd, dim3((M + 3) / 4), dim3(256), 0, s, X3, W1, b1, y1, M);
+    return hipGetLastError();
+}
+int t_red_blocks(int M) { return (M + RED_ROWS - 1) / RED_ROWS; }
+
+hipError_t t_bn_stats(const float* A, int M, int C, float momentum, double* part, float* mean, float* rstd,
+                      float* running_mean, float* running_var, hipStream_t s) {
+    const int nblk = t_red_blocks(M);
+    hipLaunchKernelGGL(k_colreduce, dim3((C + 63) / 64, nblk), dim3(256), 0, s, A, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, 0, part);
+    hipLaunchKernelGGL(k_stats_finalize, grid1(C), dim3(256), 0, s, part, nblk, A, M, C, momentum, mean, rstd,
+                       running_mean, running_var);
+    return hipGetLastError();
+}
+hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        float* h, int M, int C, int relu, hipStream_t s) {
+    hipLaunchKernelGGL(k_bn_act_fwd, grid1((size_t)M * C), dim3(256), 0, s, y, mean, rstd, gamma, beta, h,
+                       (size_t)M * C, C, relu);
+    return hipGetLastError();
+}
+// dh (in place) <- dy ; also dgamma, dbeta
+hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean, const float* rstd,
+                    const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
+                    float* dbeta, hipStream_t s) {
+    const int nblk = t_red_blocks(M);
+    hipLaunchKernelGGL(k_colreduce, dim3((C + 63) / 64, nblk), dim3(256), 0, s, (const float*)dh, h, y, mean, rstd, M,
+                       C, 1, part);
+    hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta);
+    hipLaunchKernelGGL(k_bn_bwd_dense, grid1((size_t)M * C), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, m1, m2,
+                       (size_t)M * C, C);
+    return hipGetLastError();
+}
+hipError_t t_maxpool_bn(const float* y3, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        int B, int P, int C, int relu, float* pooled, int* arg, hipStream_t s) {
+    hipLaunchKernelGGL(k_maxpool_bn, dim3(C / 64, B), dim3(256), 0, s, y3, mean, rstd, gamma, beta, P, C, relu, pooled,
+                       arg);
+    return hipGetLastError();
+}
+// y3 (in place) <- dy3 ; also dgamma, dbeta
+hipError_t t_pool_bwd(float* y3, const float* dpooled, const float* pooled, const int* arg, const float* mean,
+                      const float* rstd, const float* gamma, int B, int P, int C, int relu, float* m1, float* m2,
+                      float* dgamma, float* dbeta, hipStream_t s) {
+    hipLaunchKernelGGL(k_pool_bwd_reduce, grid1(C), dim3(256), 0, s, dpooled, pooled, arg, (const float*)y3, mean, rstd,
+                       B, P, C, relu, m1, m2, dgamma, dbeta);
+    hipLaunchKernelGGL(k_pool_bwd_dense, grid1((size_t)B * P * C), dim3(256), 0, s, y3, mean, rstd, gamma,
+                       (const float*)m1, (const float*)m2, (size_t)B * P * C, C);
+    hipLaunchKernelGGL(k_pool_bwd_sparse, grid1((size_t)B * C), dim3(256), 0, s, y3, dpooled, pooled, arg, rstd, gamma,
+                       B, P, C, relu);
+    return hipGetLastError();
+}
+hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s) {
+    if (Kout % 64 != 0 || N % 32 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gemm_nn_kernel, dim3(Kout / 64, (M + 63) / 64), dim3(256), 0, s, dY, W, dX, M, N, Kout);
+    return hipGetLastError();
+}
+int t_tn_chunks(int M) { return (M + TN_ROWS_PER_CHUNK - 1) / TN_ROWS_PER_CHUNK; }
+
+hipError_t t_gemm_tn(const float* dY, const float* Hm, float* part, float* dW, int M, int N, int K, hipStream_t s) {
+    if (N % 64 != 0 || K % 64 != 0) return hipErrorInvalidValue;
+    const int chunks = t_tn_chunks(M);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(K / 64, N / 64, chunks), dim3(256), 0, s, dY, Hm, part, M, N, K,
+                       TN_ROWS_PER_CHUNK);
+    hipLaunchKernelGGL(k_reduce_chunks, grid1((size_t)N * K), dim3(256), 0, s, (const float*)part, chunks,
+                       (size_t)N * K, dW);
+    return hipGetLastError();
+}
+hipError_t t_conv1_bwd(const float* dy1, const float* X3, const float* W1, int M, double* part, float* dW1,
+                       float* dX3, hipStream_t s) {
+    const int nblk = t_red_blocks(M);
+    hipLaunchKernelGGL(k_conv1_wgrad, dim3(nblk), dim3(256), 0, s, dy1, X3, M, part);
+    hipLaunchKernelGGL(k_reduce_double, grid1(192), dim3(256), 0, s, (const double*)part, nblk, 192, dW1);
+    if (dX3 != nullptr) hipLaunchKernelGGL(k_conv1_dgrad, dim3((M + 3) / 4), dim3(256), 0, s, dy1, W1, dX3, M);
+    return hipGetLastError();
+}
+hipError_t t_trans_grad(const float* x, const float* dX3, int B, int P, const float* dtrans_ext, float* dtrans,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(k_trans_grad, dim3(B), dim3(256), 0, s, x, dX3, P, dtrans_ext, dtrans);
+    return hipGetLastError();
+}
+hipError_t t_small_bwd(const float* dZ, const float* A, const float* W, float* dA, float* dW, float* db, int M, int N,
+                       int K, hipStream_t s) {
+    hipLaunchKernelGGL(k_small_dgrad, grid1((size_t)M * K), dim3(256), 0, s, dZ, W, dA, M, N, K);
+    hipLaunchKernelGGL(k_small_wgrad, grid1((size_t)N * K), dim3(256), 0, s, dZ, A, dW, db, M, N, K);
+    return hipGetLastError();
+}
+hipError_t t_fill(float* p, size_t n, float v, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill, grid1(n), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+hipError_t t_logsoftmax_bwd(const float* logp, const float* dlogp, float* dlogits, int B, int k, hipStream_t s) {
+    hipLaunchKernelGGL(k_logsoftmax_bwd, grid1(B), dim3(256), 0, s, logp, dlogp, dlogits, B, k);
+    return hipGetLastError();
+}
+hipError_t t_nll_loss(const float* logp, const long long* target, int B, int k, float* loss, float* dlogp,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_nll_loss, dim3(1), dim3(256), 0, s, logp, target, B, k, loss, dlogp);
+    return hipGetLastError();
+}
+hipError_t t_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                  int step, float grad_scale, hipStream_t s) {
+    // bias corrections in double, as torch computes them in Python floats
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2_sqrt = sqrt(1.0 - pow((double)b2, (double)step));
+    hipLaunchKernelGGL(k_adam, grid1(n), dim3(256), 0, s, p, g, m, v, n, (float)((double)lr / bc1), b1, b2, eps,
+                       (float)bc2_sqrt, grad_scale);
+    return hipGetLastError();
+}
+
+}  // namespace pngpd

@@ -1,0 +1,288 @@
+// C-ABI of the training step: sequencing of the train.hip kernels over a caller-owned workspace.
+#include <hip/hip_runtime.h>
+
+#include "api_common.h"
+#include "kernels.h"
+#include "pngpd.h"
+
+namespace {
+
+using pngpd::fail;
+
+constexpr int C1 = pngpd::C1, C2 = pngpd::C2, C3 = pngpd::C3;
+
+// bump allocator over the workspace; every block is 256-byte aligned
+struct Bump {
+    char* base;
+    size_t off = 0;
+    explicit Bump(void* b) : base((char*)b) {}
+    template <typename T>
+    T* take(size_t n) {
+        T* p = (T*)(base + off);
+        off += (n * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+struct StackWs {
+    float *X3, *y1, *h1, *y2, *h2, *y3, *pooled, *dh2, *dh1, *dX3;
+    int* arg;
+    float *mean[3], *rstd[3];
+};
+
+struct FcWs {
+    float *z1, *a1, *z2, *a2, *da2, *da1, *din;
+    float *mean[2], *rstd[2];
+};
+
+struct TrainWs {
+    StackWs stn, trunk;
+    FcWs stn_fc, head_fc;
+    double* part;
+    float *tn_part, *m1, *m2, *dlogits, *dtrans, *trans;
+    size_t bytes;
+
+    TrainWs(void* base, int B, int P, int k) {
+        Bump a(base);
+        const size_t M = (size_t)B * P;
+        for (StackWs* s : {&stn, &trunk}) {
+            s->X3 = a.take<float>(M * 3);
+            s->y1 = a.take<float>(M * C1);
+            s->h1 = a.take<float>(M * C1);
+            s->y2 = a.take<float>(M * C2);
+            s->h2 = a.take<float>(M * C2);
+            s->y3 = a.take<float>(M * C3);
+            s->pooled = a.take<float>((size_t)B * C3);
+            s->arg = a.take<int>((size_t)B * C3);
+            s->dh2 = a.take<float>(M * C2);
+            s->dh1 = a.take<float>(M * C1);
+            s->dX3 = a.take<float>(M * 3);
+            const int ch[3] = {C1, C2, C3};
+            for (int i = 0; i < 3; ++i) {
+                s->mean[i] = a.take<float>(ch[i]);
+                s->rstd[i] = a.take<float>(ch[i]);
+            }
+        }
+        for (FcWs* f : {&stn_fc, &head_fc}) {
+            f->z1 = a.take<float>((size_t)B * 512);
+            f->a1 = a.take<float>((size_t)B * 512);
+            f->z2 = a.take<float>((size_t)B * 256);
+            f->a2 = a.take<float>((size_t)B * 256);
+            f->da2 = a.take<float>((size_t)B * 256);
+            f->da1 = a.take<float>((size_t)B * 512);
+            f->din = a.take<float>((size_t)B * 1024);
+            f->mean[0] = a.take<float>(512);
+            f->rstd[0] = a.take<float>(512);
+            f->mean[1] = a.take<float>(256);
+            f->rstd[1] = a.take<float>(256);
+        }
+        const size_t nblk = (size_t)pngpd::t_red_blocks((int)M);
+        part = a.take<double>(nblk * 2 * C3);
+        const size_t chunks = (size_t)pngpd::t_tn_chunks((int)M);
+        size_t tn = chunks * (size_t)C3 * C2;
+        if (tn < (size_t)512 * 1024) tn = (size_t)512 * 1024;
+        tn_part = a.take<float>(tn);
+        m1 = a.take<float>(C3);
+        m2 = a.take<float>(C3);
+        dlogits = a.take<float>((size_t)B * 16);
+        dtrans = a.take<float>((size_t)B * 9);
+        trans = a.take<float>((size_t)B * 9);
+        (void)k;
+        bytes = a.off;
+    }
+};
+
+// slot helpers
+inline float* slot(float* const* t, int unit, int field) { return t[unit * PNGPD_FIELDS + field]; }
+inline const float* cslot(const float* const* t, int unit, int field) { return t[unit * PNGPD_FIELDS + field]; }
+
+int check_tables(float* const* params, bool need_running) {
+    for (int u = 0; u < PNGPD_UNITS; ++u) {
+        const bool has_bn = (u != PNGPD_U_STN_FC3 && u != PNGPD_U_FC3);
+        if (!slot(params, u, PNGPD_F_WEIGHT) || !slot(params, u, PNGPD_F_BIAS))
+            return fail(PNGPD_ERR_INVALID, "training table: unit %d has no weight/bias", u);
+        if (has_bn && (!slot(params, u, PNGPD_F_BN_WEIGHT) || !slot(params, u, PNGPD_F_BN_BIAS)))
+            return fail(PNGPD_ERR_INVALID, "training table: unit %d lacks BatchNorm affine tensors", u);
+        if (has_bn && need_running && (!slot(params, u, PNGPD_F_BN_MEAN) || !slot(params, u, PNGPD_F_BN_VAR)))
+            return fail(PNGPD_ERR_INVALID, "training table: unit %d lacks running statistics", u);
+    }
+    return PNGPD_OK;
+}
+
+int check_shape(int B, int P, int k, const void* ws, size_t ws_bytes) {
+    if (B < 2) return fail(PNGPD_ERR_SHAPE, "train-mode BatchNorm needs a batch of at least 2, got %d", B);
+    if (P < 1 || k < 2 || k > 16) return fail(PNGPD_ERR_SHAPE, "training: P=%d k=%d", P, k);
+    if ((size_t)B * P > (size_t)1 << 30) return fail(PNGPD_ERR_SHAPE, "training: B*P too large");
+    if (!ws || ws_bytes < pngpd_train_workspace_bytes(B, P, k))
+        return fail(PNGPD_ERR_WORKSPACE, "training workspace of %zu bytes is smaller than the %zu needed", ws_bytes,
+                    pngpd_train_workspace_bytes(B, P, k));
+    return PNGPD_OK;
+}
+
+// conv1 -> bn -> relu -> conv2 -> bn -> relu -> conv3 -> bn (-> relu) -> max over points
+int fwd_stack(StackWs& S, float* const* p, int u1, const float* x, const float* trans, int B, int P, int relu_out,
+              float momentum, double* part, hipStream_t s) {
+    const int M = B * P;
+    const int ch[3] = {C1, C2, C3};
+    float* ys[3] = {S.y1, S.y2, S.y3};
+    float* hs[2] = {S.h1, S.h2};
+    HIP_TRY(pngpd::t_points_to_rows(x, trans, S.X3, B, P, s));
+    HIP_TRY(pngpd::t_conv1_fwd(S.X3, slot(p, u1, PNGPD_F_WEIGHT), slot(p, u1, PNGPD_F_BIAS), S.y1, M, s));
+    for (int l = 0; l < 3; ++l) {
+        const int u = u1 + l;
+        if (l > 0)
+            HIP_TRY(pngpd::launch_fc_f32(hs[l - 1], slot(p, u, PNGPD_F_WEIGHT), slot(p, u, PNGPD_F_BIAS), ys[l], M,
+                                         ch[l], ch[l - 1], 0, s));
+        HIP_TRY(pngpd::t_bn_stats(ys[l], M, ch[l], momentum, part, S.mean[l], S.rstd[l], slot(p, u, PNGPD_F_BN_MEAN),
+                                  slot(p, u, PNGPD_F_BN_VAR), s));
+        if (l < 2)
+            HIP_TRY(pngpd::t_bn_act_fwd(ys[l], S.mean[l], S.rstd[l], slot(p, u, PNGPD_F_BN_WEIGHT),
+                                        slot(p, u, PNGPD_F_BN_BIAS), hs[l], M, ch[l], 1, s));
+    }
+    HIP_TRY(pngpd::t_maxpool_bn(S.y3, S.mean[2], S.rstd[2], slot(p, u1 + 2, PNGPD_F_BN_WEIGHT),
+                                slot(p, u1 + 2, PNGPD_F_BN_BIAS), B, P, C3, relu_out, S.pooled, S.arg, s));
+    return PNGPD_OK;
+}
+
+// linear -> bn -> relu -> linear -> bn -> relu -> linear (+ identity | log_softmax)
+int fwd_fc(FcWs& F, float* const* p, int u1, const float* in, float* out, int B, int n_last, int tail, float momentum,
+           double* part, hipStream_t s) {
+    const int n[2] = {512, 256}, kk[2] = {1024, 512};
+    float* zs[2] = {F.z1, F.z2};
+    float* as[2] = {F.a1, F.a2};
+    const float* cur = in;
+    for (int l = 0; l < 2; ++l) {
+        const int u = u1 + l;
+        HIP_TRY(pngpd::launch_fc_f32(cur, slot(p, u, PNGPD_F_WEIGHT), slot(p, u, PNGPD_F_BIAS), zs[l], B, n[l], kk[l],
+                                     0, s));
+        HIP_TRY(pngpd::t_bn_stats(zs[l], B, n[l], momentum, part, F.mean[l], F.rstd[l], slot(p, u, PNGPD_F_BN_MEAN),
+                                  slot(p, u, PNGPD_F_BN_VAR), s));
+        HIP_TRY(pngpd::t_bn_act_fwd(zs[l], F.mean[l], F.rstd[l], slot(p, u, PNGPD_F_BN_WEIGHT),
+                                    slot(p, u, PNGPD_F_BN_BIAS), as[l], B, n[l], 1, s));
+        cur = as[l];
+    }
+    HIP_TRY(pngpd::launch_fc_tail(F.a2, slot(p, u1 + 2, PNGPD_F_WEIGHT), slot(p, u1 + 2, PNGPD_F_BIAS), out, B, n_last,
+                                  256, tail, s));
+    return PNGPD_OK;
+}
+
+int bwd_fc(FcWs& F, const float* const* p, float* const* g, int u1, const float* in, const float* dOut, int B,
+           int n_last, TrainWs& W, hipStream_t s) {
+    // last layer (no BatchNorm): real bias gradient
+    HIP_TRY(pngpd::t_small_bwd(dOut, F.a2, cslot(p, u1 + 2, PNGPD_F_WEIGHT), F.da2, slot(g, u1 + 2, PNGPD_F_WEIGHT),
+                               slot(g, u1 + 2, PNGPD_F_BIAS), B, n_last, 256, s));
+    // layer 2
+    HIP_TRY(pngpd::t_bn_bwd(F.da2, F.a2, F.z2, F.mean[1], F.rstd[1], cslot(p, u1 + 1, PNGPD_F_BN_WEIGHT), B, 256,
+                            W.part, W.m1, W.m2, slot(g, u1 + 1, PNGPD_F_BN_WEIGHT), slot(g, u1 + 1, PNGPD_F_BN_BIAS), s));
+    HIP_TRY(pngpd::t_gemm_tn(F.da2, F.a1, W.tn_part, slot(g, u1 + 1, PNGPD_F_WEIGHT), B, 256, 512, s));
+    HIP_TRY(pngpd::t_fill(slot(g, u1 + 1, PNGPD_F_BIAS), 256, 0.f, s));
+    HIP_TRY(pngpd::t_gemm_nn(F.da2, cslot(p, u1 + 1, PNGPD_F_WEIGHT), F.da1, B, 256, 512, s));
+    // layer 1
+    HIP_TRY(pngpd::t_bn_bwd(F.da1, F.a1, F.z1, F.mean[0], F.rstd[0], cslot(p, u1, PNGPD_F_BN_WEIGHT), B, 512, W.part,
+                            W.m1, W.m2, slot(g, u1, PNGPD_F_BN_WEIGHT), slot(g, u1, PNGPD_F_BN_BIAS), s));
+    HIP_TRY(pngpd::t_gemm_tn(F.da1, in, W.tn_part, slot(g, u1, PNGPD_F_WEIGHT), B, 512, 1024, s));
+    HIP_TRY(pngpd::t_fill(slot(g, u1, PNGPD_F_BIAS), 512, 0.f, s));
+    HIP_TRY(pngpd::t_gemm_nn(F.da1, cslot(p, u1, PNGPD_F_WEIGHT), F.din, B, 512, 1024, s));
+    return PNGPD_OK;
+}
+
+int bwd_stack(StackWs& S, const float* const* p, float* const* g, int u1, const float* dpooled, int B, int P,
+              int relu_out, bool need_dX3, TrainWs& W, hipStream_t s) {
+    const int M = B * P;
+    // conv3 / bn3 / max-pool: y3 becomes dy3 in place
+    HIP_TRY(pngpd::t_pool_bwd(S.y3, dpooled, S.pooled, S.arg, S.mean[2], S.rstd[2], cslot(p, u1 + 2, PNGPD_F_BN_WEIGHT), B,
+                              P, C3, relu_out, W.m1, W.m2, slot(g, u1 + 2, PNGPD_F_BN_WEIGHT),
+                              slot(g, u1 + 2, PNGPD_F_BN_BIAS), s));
+    HIP_TRY(pngpd::t_gemm_tn(S.y3, S.h2, W.tn_part, slot(g, u1 + 2, PNGPD_F_WEIGHT), M, C3, C2, s));
+    HIP_TRY(pngpd::t_fill(slot(g, u1 + 2, PNGPD_F_BIAS), C3, 0.f, s));
+    HIP_TRY(pngpd::t_gemm_nn(S.y3, cslot(p, u1 + 2, PNGPD_F_WEIGHT), S.dh2, M, C3, C2, s));
+    // conv2 / bn2
+    HIP_TRY(pngpd::t_bn_bwd(S.dh2, S.h2, S.y2, S.mean[1], S.rstd[1], cslot(p, u1 + 1, PNGPD_F_BN_WEIGHT), M, C2, W.part,
+                            W.m1, W.m2, slot(g, u1 + 1, PNGPD_F_BN_WEIGHT), slot(g, u1 + 1, PNGPD_F_BN_BIAS), s));
+    HIP_TRY(pngpd::t_gemm_tn(S.dh2, S.h1, W.tn_part, slot(g, u1 + 1, PNGPD_F_WEIGHT), M, C2, C1, s));
+    HIP_TRY(pngpd::t_fill(slot(g, u1 + 1, PNGPD_F_BIAS), C2, 0.f, s));
+    HIP_TRY(pngpd::t_gemm_nn(S.dh2, cslot(p, u1 + 1, PNGPD_F_WEIGHT), S.dh1, M, C2, C1, s));
+    // conv1 / bn1
+    HIP_TRY(pngpd::t_bn_bwd(S.dh1, S.h1, S.y1, S.mean[0], S.rstd[0], cslot(p, u1, PNGPD_F_BN_WEIGHT), M, C1, W.part,
+                            W.m1, W.m2, slot(g, u1, PNGPD_F_BN_WEIGHT), slot(g, u1, PNGPD_F_BN_BIAS), s));
+    HIP_TRY(pngpd::t_conv1_bwd(S.dh1, S.X3, cslot(p, u1, PNGPD_F_WEIGHT), M, W.part, slot(g, u1, PNGPD_F_WEIGHT),
+                               need_dX3 ? S.dX3 : nullptr, s));
+    HIP_TRY(pngpd::t_fill(slot(g, u1, PNGPD_F_BIAS), C1, 0.f, s));
+    return PNGPD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pngpd_train_workspace_bytes(int B, int P, int k) {
+    if (B < 1 || P < 1) return 0;
+    TrainWs w(nullptr, B, P, k);
+    return w.bytes;
+}
+
+int pngpd_train_forward(int B, int P, int k, const float* x_dev, float* const* params_dev, int n_slots,
+                        float momentum, float* logp_dev, float* trans_dev, float* feat_dev, void* workspace_dev,
+                        size_t workspace_bytes, void* stream) {
+    if (!x_dev || !params_dev || !logp_dev) return fail(PNGPD_ERR_INVALID, "pngpd_train_forward: NULL argument");
+    if (n_slots != PNGPD_SLOTS) return fail(PNGPD_ERR_INVALID, "training table must have %d slots", PNGPD_SLOTS);
+    int rc = check_shape(B, P, k, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    if ((rc = check_tables(params_dev, true))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    TrainWs W(workspace_dev, B, P, k);
+    float* trans = trans_dev ? trans_dev : W.trans;
+    if ((rc = fwd_stack(W.stn, params_dev, PNGPD_U_STN_CONV1, x_dev, nullptr, B, P, 1, momentum, W.part, s))) return rc;
+    if ((rc = fwd_fc(W.stn_fc, params_dev, PNGPD_U_STN_FC1, W.stn.pooled, trans, B, 9, pngpd::FC_TAIL_ADD_IDENTITY,
+                     momentum, W.part, s)))
+        return rc;
+    if ((rc = fwd_stack(W.trunk, params_dev, PNGPD_U_FEAT_CONV1, x_dev, trans, B, P, 0, momentum, W.part, s))) return rc;
+    if ((rc = fwd_fc(W.head_fc, params_dev, PNGPD_U_FC1, W.trunk.pooled, logp_dev, B, k, pngpd::FC_TAIL_LOG_SOFTMAX,
+                     momentum, W.part, s)))
+        return rc;
+    if (feat_dev)
+        HIP_TRY(hipMemcpyAsync(feat_dev, W.trunk.pooled, (size_t)B * C3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return PNGPD_OK;
+}
+
+int pngpd_train_backward(int B, int P, int k, const float* x_dev, const float* const* params_dev,
+                         float* const* grads_dev, int n_slots, const float* logp_dev, const float* dlogp_dev,
+                         const float* dtrans_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+    if (!x_dev || !params_dev || !grads_dev || !logp_dev || !dlogp_dev)
+        return fail(PNGPD_ERR_INVALID, "pngpd_train_backward: NULL argument");
+    if (n_slots != PNGPD_SLOTS) return fail(PNGPD_ERR_INVALID, "training table must have %d slots", PNGPD_SLOTS);
+    int rc = check_shape(B, P, k, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    if ((rc = check_tables((float* const*)params_dev, false))) return rc;
+    if ((rc = check_tables(grads_dev, false))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    TrainWs W(workspace_dev, B, P, k);
+    HIP_TRY(pngpd::t_logsoftmax_bwd(logp_dev, dlogp_dev, W.dlogits, B, k, s));
+    if ((rc = bwd_fc(W.head_fc, params_dev, grads_dev, PNGPD_U_FC1, W.trunk.pooled, W.dlogits, B, k, W, s))) return rc;
+    if ((rc = bwd_stack(W.trunk, params_dev, grads_dev, PNGPD_U_FEAT_CONV1, W.head_fc.din, B, P, 0, true, W, s)))
+        return rc;
+    HIP_TRY(pngpd::t_trans_grad(x_dev, W.trunk.dX3, B, P, dtrans_dev, W.dtrans, s));
+    if ((rc = bwd_fc(W.stn_fc, params_dev, grads_dev, PNGPD_U_STN_FC1, W.stn.pooled, W.dtrans, B, 9, W, s))) return rc;
+    if ((rc = bwd_stack(W.stn, params_dev, grads_dev, PNGPD_U_STN_CONV1, W.stn_fc.din, B, P, 1, false, W, s))) return rc;
+    return PNGPD_OK;
+}
+
+int pngpd_nll_loss(const float* logp_dev, const int64_t* target_dev, int B, int k, float* loss_dev, float* dlogp_dev,
+                   void* stream) {
+    if (!logp_dev || !target_dev || !loss_dev || !dlogp_dev) return fail(PNGPD_ERR_INVALID, "pngpd_nll_loss: NULL argument");
+    if (B < 1 || k < 2) return fail(PNGPD_ERR_SHAPE, "pngpd_nll_loss: B=%d k=%d", B, k);
+    HIP_TRY(pngpd::t_nll_loss(logp_dev, (const long long*)target_dev, B, k, loss_dev, dlogp_dev, (hipStream_t)stream));
+    return PNGPD_OK;
+}
+
+int pngpd_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
+                    float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+    if (!params_dev || !grads_dev || !exp_avg_dev || !exp_avg_sq_dev)
+        return fail(PNGPD_ERR_INVALID, "pngpd_adam_step: NULL argument");
+    if (n < 1 || step < 1) return fail(PNGPD_ERR_SHAPE, "pngpd_adam_step: n=%lld step=%d", (long long)n, step);
+    HIP_TRY(pngpd::t_adam(params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, (size_t)n, lr, beta1, beta2, eps, step,
+                          grad_scale, (hipStream_t)stream));
+    return PNGPD_OK;
+}
+
+}  // extern "C"

@@ -22,6 +22,15 @@ from . import _lib
 
 _DEFAULT_PRECISION = os.environ.get("PNGPD_PRECISION", "fp32")
 
+# Bumped whenever library kernels change parameters or running statistics behind torch's back
+# (training step, fused Adam): torch's per-tensor version counters do not see those writes.
+_GENERATION = [0]
+
+
+def invalidate_packed_weights() -> None:
+    """Force every module to re-fold and re-pack its weights on the next eval-mode forward."""
+    _GENERATION[0] += 1
+
 
 class _Handle:
     """Owns one pngpd_model (device weights) and the per-batch-size workspaces."""
@@ -82,7 +91,7 @@ class _HipBacked(nn.Module):
         h = self.__dict__.get("_hip")
         if h is None or h.device != device:
             h = self.__dict__["_hip"] = _Handle(device, self.num_points, self._num_classes(), self._PARTS)
-        sig = tuple((t.data_ptr(), t._version) for t in self._tensors())
+        sig = (_GENERATION[0],) + tuple((t.data_ptr(), t._version) for t in self._tensors())
         if h.signature != sig:
             self._upload(h)
             h.signature = sig
@@ -115,8 +124,8 @@ class _HipBacked(nn.Module):
             raise RuntimeError("pointnetgpd_amd runs on MI355X only: move the module and its input to a "
                                "ROCm device (there is no CPU path)")
         if self.training:
-            raise RuntimeError("train-mode forward goes through pointnetgpd_amd.training (batch statistics); "
-                               "call .eval() for inference")
+            raise RuntimeError("train-mode forward (batch statistics) is implemented for PointNetCls as a whole "
+                               "(pointnetgpd_amd.training); call .eval() for inference")
         chan_dim, pts_dim = (1, 2) if layout == _lib.LAYOUT_C3P else (2, 1)
         if x.shape[chan_dim] != 3:
             raise ValueError(f"input_chann must be 3, got {x.shape[chan_dim]}")
@@ -230,6 +239,10 @@ class PointNetCls(_HipBacked):
         return self.fc3.out_features
 
     def forward(self, x):
+        if self.training:
+            # batch-statistics BatchNorm + autograd (main_1v.py:266-272)
+            from .training import forward_train_mode
+            return forward_train_mode(self, x)
         logp, trans, _ = self._infer(x, _lib.LAYOUT_C3P, True, False)
         return logp, trans
 

@@ -1,0 +1,210 @@
+"""Training step of the reference (main_1v.py:237-302) on the HIP path.
+
+Two ways in, same kernels:
+
+* drop-in: a PointNetCls in train() mode called as ``output, _ = model(data)`` goes through
+  `TrainFunction`, a torch.autograd.Function whose forward/backward call pngpd_train_forward /
+  pngpd_train_backward; ``F.nll_loss(output, target).backward()`` and ``torch.optim.Adam`` work
+  unchanged (main_1v.py:266-274).
+* fused: `Trainer.step(data, target)` keeps all parameters, gradients and Adam moments in flat
+  buffers, runs forward, NLL, backward, ONE all-reduce of the flat gradient bucket over RCCL when
+  several ranks train data-parallel, and a fused Adam update.  BatchNorm statistics stay
+  per-replica, like nn.DataParallel in the reference (main_1v.py:224).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .pointnet import invalidate_packed_weights
+
+BN_MOMENTUM = 0.1
+
+
+def _unit_tensors(model):
+    """(params table order) unit -> [weight, bias, bn_weight, bn_bias, running_mean, running_var]."""
+    out = []
+    units = model._units()
+    for uname in _lib.UNITS:
+        layer, bn = units[uname]
+        row = [layer.weight, layer.bias]
+        row += [bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [None] * 4
+        out.append(row)
+    return out
+
+
+def _table(rows, getter):
+    t = (ctypes.c_void_p * _lib.SLOTS)()
+    for ui, row in enumerate(rows):
+        for fi, x in enumerate(row):
+            v = getter(x, fi) if x is not None else None
+            if v is not None:
+                if v.dtype != torch.float32 or not v.is_contiguous() or not v.is_cuda:
+                    raise ValueError("training needs contiguous float32 ROCm tensors")
+                t[ui * len(_lib.FIELDS) + fi] = v.data_ptr()
+    return t
+
+
+def _bump_num_batches(model):
+    bufs = [m.num_batches_tracked for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+    torch._foreach_add_(bufs, 1)
+
+
+def _check(model, x):
+    if not x.is_cuda:
+        raise RuntimeError("pointnetgpd_amd trains on MI355X only (there is no CPU path)")
+    if x.dim() != 3 or x.shape[1] != 3 or x.shape[2] != model.num_points:
+        raise ValueError(f"expected data [B,3,{model.num_points}], got {tuple(x.shape)}")
+    if x.shape[0] < 2:
+        raise ValueError("train-mode BatchNorm needs more than one sample per batch (main_1v.py:258)")
+    return x.detach().to(torch.float32).contiguous()
+
+
+def train_forward(model, x, ws=None):
+    """Train-mode forward; returns (logp, trans, workspace).  Updates running statistics."""
+    lib = _lib.load()
+    x = _check(model, x)
+    B, _, P = x.shape
+    k = model.fc3.out_features
+    dev = x.device
+    nbytes = lib.pngpd_train_workspace_bytes(B, P, k)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rows = _unit_tensors(model)
+    params = _table(rows, lambda t, fi: t.data)
+    logp = torch.empty((B, k), dtype=torch.float32, device=dev)
+    trans = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.pngpd_train_forward(B, P, k, ctypes.c_void_p(x.data_ptr()), params, _lib.SLOTS, BN_MOMENTUM,
+                                           ctypes.c_void_p(logp.data_ptr()), ctypes.c_void_p(trans.data_ptr()), None,
+                                           ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream))
+    _bump_num_batches(model)
+    invalidate_packed_weights()        # running statistics changed under torch's version counters
+    return logp, trans, ws, x
+
+
+def train_backward(model, x, logp, dlogp, dtrans, ws, grad_of):
+    """Backward of train_forward.  grad_of(param) -> tensor that receives that parameter's gradient."""
+    lib = _lib.load()
+    B, _, P = x.shape
+    k = model.fc3.out_features
+    rows = _unit_tensors(model)
+    params = _table(rows, lambda t, fi: t.data)
+    grads = _table(rows, lambda t, fi: grad_of(t) if fi < 4 else None)
+    dlogp = dlogp.to(torch.float32).contiguous()
+    dtrans_p = None
+    if dtrans is not None:
+        dtrans = dtrans.to(torch.float32).contiguous()
+        dtrans_p = ctypes.c_void_p(dtrans.data_ptr())
+    with torch.cuda.device(x.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(lib.pngpd_train_backward(B, P, k, ctypes.c_void_p(x.data_ptr()), params, grads, _lib.SLOTS,
+                                            ctypes.c_void_p(logp.data_ptr()), ctypes.c_void_p(dlogp.data_ptr()),
+                                            dtrans_p, ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream))
+
+
+class TrainFunction(torch.autograd.Function):
+    """autograd bridge: forward(model, x, *parameters) -> (logp, trans)."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        logp, trans, ws, xc = train_forward(model, x)
+        ctx.model, ctx.ws, ctx.x, ctx.logp, ctx.params = model, ws, xc, logp, params
+        return logp, trans
+
+    @staticmethod
+    def backward(ctx, dlogp, dtrans):
+        grads = {id(p): torch.empty_like(p) for p in ctx.params}
+        if dlogp is None:
+            dlogp = torch.zeros_like(ctx.logp)
+        train_backward(ctx.model, ctx.x, ctx.logp, dlogp, dtrans, ctx.ws, lambda p: grads[id(p)])
+        ctx.ws = None
+        return (None, None) + tuple(grads[id(p)] for p in ctx.params)
+
+
+def forward_train_mode(model, x):
+    """What PointNetCls.forward does in train() mode."""
+    params = [t for row in _unit_tensors(model) for t in row[:4] if t is not None]
+    return TrainFunction.apply(model, x, *params)
+
+
+def nll_loss(logp, target):
+    """(loss[1], dlogp[B,k]) of F.nll_loss(logp, target) with mean reduction, on the device."""
+    lib = _lib.load()
+    B, k = logp.shape
+    target = target.to(torch.int64).reshape(-1).contiguous()
+    loss = torch.empty(1, dtype=torch.float32, device=logp.device)
+    dlogp = torch.empty_like(logp)
+    with torch.cuda.device(logp.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(logp.device).cuda_stream)
+        _lib.check(lib.pngpd_nll_loss(ctypes.c_void_p(logp.data_ptr()), ctypes.c_void_p(target.data_ptr()), B, k,
+                                      ctypes.c_void_p(loss.data_ptr()), ctypes.c_void_p(dlogp.data_ptr()), stream))
+    return loss, dlogp
+
+
+def step_lr(base_lr: float, epoch: int, step_size: int = 30, gamma: float = 0.5) -> float:
+    """Learning rate the reference trains epoch `epoch` (0-based) with: StepLR(30, 0.5) whose
+    step() is called at the START of every epoch (main_1v.py:233, 239)."""
+    return base_lr * gamma ** ((epoch + 1) // step_size)
+
+
+class Trainer:
+    """Flat-buffer trainer: Adam(lr=0.005, betas=(0.9, 0.999), eps=1e-8) as in main_1v.py:226."""
+
+    def __init__(self, model, lr=0.005, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+        self.model = model
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.group = process_group
+        self.step_count = 0
+        self.params = [p for p in model.parameters()]
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("move the model to a ROCm device before building a Trainer")
+        n = sum(p.numel() for p in self.params)
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        self._gview = {}
+        for p in self.params:
+            k = p.numel()
+            self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + k].view_as(p)         # parameters become views of the bucket
+            g = self.flat_g[off:off + k].view_as(p)
+            p.grad = g
+            self._gview[id(p)] = g
+            off += k
+        self._ws = None
+
+    def world_size(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
+
+    def step(self, data, target):
+        """One training step; returns (loss[1] tensor, logp[B,k])."""
+        model = self.model
+        if not model.training:
+            raise RuntimeError("Trainer.step needs model.train()")
+        logp, _, self._ws, x = train_forward(model, data, self._ws)
+        loss, dlogp = nll_loss(logp, target)
+        train_backward(model, x, logp, dlogp, None, self._ws, lambda p: self._gview[id(p)])
+        ws = self.world_size()
+        if ws > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)   # the one collective
+        self.step_count += 1
+        lib = _lib.load()
+        dev = self.flat_p.device
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.pngpd_adam_step(ctypes.c_void_p(self.flat_p.data_ptr()), ctypes.c_void_p(self.flat_g.data_ptr()),
+                                           ctypes.c_void_p(self.exp_avg.data_ptr()),
+                                           ctypes.c_void_p(self.exp_avg_sq.data_ptr()), self.flat_p.numel(), self.lr,
+                                           self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / ws, stream))
+        invalidate_packed_weights()    # the fused update bypasses torch's version counters
+        return loss, logp

@@ -1,0 +1,169 @@
+"""GPU parity of the training step (main_1v.py:262-274) against the reference's golden one-step
+vectors and against the CPU oracle: loss, gradients, post-Adam parameters, running statistics."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import pointnet_oracle as po
+from pointnetgpd_amd import synth
+from pointnetgpd_amd.pointnet import PointNetCls
+from pointnetgpd_amd.training import Trainer, nll_loss, step_lr
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+def load_golden():
+    d = np.load(os.path.join(GOLDEN, "train_step_p750_k2.npz"))
+    P, k, seed, B = (int(v) for v in d["meta"])
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
+    target = torch.from_numpy(d["target"])
+    return d, P, k, seed, B, float(d["gain"]), x, target
+
+
+def hip_train_model(P, k, seed, gain):
+    m = PointNetCls(P, 3, k)
+    m.load_state_dict(synth.torch_state_dict(seed, k, 1.0, gain))
+    return m.cuda().train()
+
+
+def test_autograd_path_matches_reference_golden_step():
+    """output,_ = model(data); F.nll_loss(...).backward(); torch.optim.Adam step - unchanged caller code."""
+    d, P, k, seed, B, gain, x, target = load_golden()
+    m = hip_train_model(P, k, seed, gain)
+    opt = torch.optim.Adam(m.parameters(), lr=0.005)
+    opt.zero_grad()
+    out, _ = m(x.cuda())
+    loss = F.nll_loss(out, target.cuda())
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) < 2e-5
+    np.testing.assert_allclose(out.detach().cpu().numpy(), d["logp"], atol=5e-5)
+    grads = {n: p.grad.detach().cpu().numpy() for n, p in m.named_parameters()}
+    worst = 0.0
+    for key in d.files:
+        if key.startswith("grad/"):
+            n = key[5:]
+            if np.abs(d[key]).max() < 1e-5:
+                # parameters whose true gradient is zero (a shift that the next BatchNorm removes):
+                # the reference holds rounding noise there
+                assert np.abs(grads[n]).max() < 1e-5, n
+                continue
+            e = rel_err(grads[n], d[key])
+            worst = max(worst, e)
+            assert e < 2e-3, (n, e)
+        elif key.startswith("gradslice/"):
+            n = key[10:]
+            g = grads[n].reshape(grads[n].shape[0], -1)
+            assert rel_err(g[:4, :8], d[key]) < 5e-3, n
+            s = d["gradsum/" + n]
+            assert abs(np.abs(g.astype(np.float64)).sum() - s[1]) / s[1] < 1e-3, n
+    print("worst relative gradient error", worst)
+    opt.step()
+    sd = {n: v.detach().cpu().numpy() for n, v in m.state_dict().items()}
+    for key in d.files:
+        if key.startswith("stat/"):
+            np.testing.assert_allclose(sd[key[5:]], d[key], rtol=1e-4, atol=1e-5, err_msg=key)
+        elif key.startswith("param/"):
+            n = key[6:]
+            clear = np.abs(d["grad/" + n]) > 1e-5          # Adam's first step is lr*sign(g): skip |g| ~ 0
+            np.testing.assert_allclose(sd[n][clear], d[key][clear], atol=2e-5, err_msg=key)
+    assert int(sd["feat.stn.bn1.num_batches_tracked"]) == 1
+
+
+def test_fused_trainer_matches_autograd_path_and_oracle():
+    P, k, seed, B = 500, 3, 77, 6
+    gain = 1.7
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
+    target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) * k).astype(np.int64))
+    sd0 = synth.torch_state_dict(seed, k, 1.0, gain)
+    # oracle: two plain torch steps on the CPU
+    oracle = po.build_cls(P, k, sd0, eval_mode=False)
+    oopt = torch.optim.Adam(oracle.parameters(), lr=0.005)
+    losses_ref = []
+    for _ in range(2):
+        oopt.zero_grad()
+        out, _ = oracle(x)
+        l = F.nll_loss(out, target)
+        l.backward()
+        oopt.step()
+        losses_ref.append(l.item())
+    # fused trainer: same two steps
+    m = PointNetCls(P, 3, k)
+    m.load_state_dict(sd0)
+    m = m.cuda().train()
+    tr = Trainer(m, lr=0.005)
+    losses = [tr.step(x.cuda(), target.cuda())[0].item() for _ in range(2)]
+    assert abs(losses[0] - losses_ref[0]) < 2e-5
+    assert abs(losses[1] - losses_ref[1]) < 5e-3          # second step sees lr*sign(g) updates of ~0 gradients
+    ref_sd = oracle.state_dict()
+    got_sd = m.state_dict()
+    for n in ("fc3.weight", "fc3.bias", "feat.stn.fc3.weight", "fc1.weight", "feat.conv3.weight"):
+        diff = (got_sd[n].cpu() - ref_sd[n]).abs()
+        assert float((diff > 1e-3).float().mean()) < 0.02, n      # all but sign-of-zero cases agree
+    np.testing.assert_allclose(got_sd["feat.bn3.running_mean"].cpu().numpy(), ref_sd["feat.bn3.running_mean"].numpy(),
+                               rtol=1e-3, atol=1e-3)
+    # eval after training re-packs the updated weights
+    m.eval()
+    oracle.eval()
+    with torch.no_grad():
+        ref_logp, _ = oracle(x)
+    logp, _ = m(x.cuda())
+    assert (logp.cpu() - ref_logp).abs().max().item() < 5e-2
+
+
+def test_nll_loss_kernel():
+    logp = torch.log_softmax(torch.randn(37, 3, generator=torch.Generator().manual_seed(0)), 1)
+    target = torch.randint(0, 3, (37,), generator=torch.Generator().manual_seed(1))
+    loss, dlogp = nll_loss(logp.cuda(), target.cuda())
+    ref = logp.clone().requires_grad_(True)
+    l = F.nll_loss(ref, target)
+    l.backward()
+    assert abs(loss.item() - l.item()) < 1e-6
+    np.testing.assert_allclose(dlogp.cpu().numpy(), ref.grad.numpy(), atol=1e-7)
+
+
+def test_batch_of_one_is_rejected_like_the_reference_skips_it():
+    m = hip_train_model(750, 2, 1, 1.7)
+    with pytest.raises(ValueError, match="more than one"):
+        m(torch.zeros(1, 3, 750, device="cuda"))
+
+
+def test_step_lr_schedule():
+    assert step_lr(0.005, 0) == 0.005 and step_lr(0.005, 28) == 0.005
+    assert step_lr(0.005, 29) == 0.0025 and step_lr(0.005, 59) == 0.00125
+
+
+def test_every_gradient_against_oracle():
+    P, k, seed, B, gain = 750, 2, 23, 5, 1.7
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
+    target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) < 0.5).astype(np.int64))
+    sd = synth.torch_state_dict(seed, k, 1.0, gain)
+    oracle = po.build_cls(P, k, sd, eval_mode=False)
+    out, _ = oracle(x)
+    F.nll_loss(out, target).backward()
+    m = hip_train_model(P, k, seed, gain)
+    out2, trans2 = m(x.cuda())
+    F.nll_loss(out2, target.cuda()).backward()
+    ref = {n: p.grad.numpy() for n, p in oracle.named_parameters()}
+    checked = 0
+    for n, p in m.named_parameters():
+        g = p.grad.cpu().numpy()
+        if np.abs(ref[n]).max() < 1e-5:
+            assert np.abs(g).max() < 1e-5, n
+        else:
+            assert rel_err(g, ref[n]) < 2e-3, (n, rel_err(g, ref[n]))
+            checked += 1
+    assert checked >= 30
+    # running statistics of all ten BatchNorm layers
+    ref_sd, got_sd = oracle.state_dict(), m.state_dict()
+    for n in ref_sd:
+        if n.endswith(("running_mean", "running_var")):
+            np.testing.assert_allclose(got_sd[n].cpu().numpy(), ref_sd[n].numpy(), rtol=2e-4, atol=2e-5, err_msg=n)
