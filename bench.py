@@ -139,6 +139,50 @@ def online_workload(args, dev, rank, n_gpus, dist):
         }), flush=True)
 
 
+def train_workload(args, dev, rank, n_gpus, dist):
+    """Config 4: training step (fwd + bwd, NLL, Adam), P=750, batch 256 per GPU, flat-bucket all-reduce."""
+    from pointnetgpd_amd.training import Trainer
+
+    B, P, k = args.train_batch, args.points, args.classes
+    model = PointNetCls(P, 3, k)
+    model.load_state_dict(synth.torch_state_dict(0, k, 0.02, 1.0), strict=True)
+    model = model.to(dev).train()
+    trainer = Trainer(model, lr=0.005)
+    x = device_points(0, B, P, rank, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(rank)
+    target = (torch.rand(B, generator=g, device=dev) < 0.5).to(torch.int64)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        trainer.step(x, target)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.step(x, target)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        flop = 3.0 * B * flop_per_candidate(P, k)
+        print(json.dumps({
+            "metric": "training samples/sec (fwd+bwd+NLL+Adam)", "value": round(n_gpus * B * args.steps / elapsed, 1),
+            "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": f"PointNetCls {k}-class train step, P={P}, batch {B} per GPU, Adam lr 0.005, "
+                                   "flat fp32 gradient bucket all-reduced over RCCL",
+                       "loss": round(float(loss.item()), 5), "approx_tflops": round(flop * args.steps / elapsed / 1e12, 2)},
+        }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,8 +193,10 @@ def main():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="score", choices=["score", "online"],
-                    help="score: headline batch scoring; online: 1M-point scene x 10k grasps crop+score")
+    ap.add_argument("--workload", default="score", choices=["score", "online", "train"],
+                    help="score: headline batch scoring; online: 1M-point scene x 10k grasps crop+score; "
+                         "train: training step, batch 256 per GPU")
+    ap.add_argument("--train-batch", type=int, default=256)
     ap.add_argument("--scene-points", type=int, default=1_000_000)
     ap.add_argument("--grasps", type=int, default=10_000)
     args = ap.parse_args()
@@ -171,8 +217,8 @@ def main():
     if n_gpus != args.gpus and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
-    if args.workload == "online":
-        online_workload(args, dev, rank, n_gpus, dist)
+    if args.workload in ("online", "train"):
+        (online_workload if args.workload == "online" else train_workload)(args, dev, rank, n_gpus, dist)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()

@@ -110,13 +110,15 @@ def test_fused_trainer_matches_autograd_path_and_oracle():
         assert float((diff > 1e-3).float().mean()) < 0.02, n      # all but sign-of-zero cases agree
     np.testing.assert_allclose(got_sd["feat.bn3.running_mean"].cpu().numpy(), ref_sd["feat.bn3.running_mean"].numpy(),
                                rtol=1e-3, atol=1e-3)
-    # eval after training re-packs the updated weights
+    # eval after training must re-fold / re-pack the weights the fused update wrote: compare with the
+    # oracle evaluated on the HIP model's OWN post-training state_dict
     m.eval()
-    oracle.eval()
+    own = po.build_cls(P, k, {n: v.detach().cpu() for n, v in m.state_dict().items()})
     with torch.no_grad():
-        ref_logp, _ = oracle(x)
+        ref_logp, _ = own(x)
     logp, _ = m(x.cuda())
-    assert (logp.cpu() - ref_logp).abs().max().item() < 5e-2
+    scale = max(1.0, float(ref_logp.abs().max()))
+    assert (logp.cpu() - ref_logp).abs().max().item() < 1e-4 * scale
 
 
 def test_nll_loss_kernel():
