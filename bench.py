@@ -266,7 +266,7 @@ def main():
     if rank == 0:
         total = float(n_gpus) * B * args.steps
         line = {
-            "metric": "grasp candidates scored/sec at N=750",
+            "metric": f"grasp candidates scored/sec at N={P}",
             "value": round(total / elapsed, 1),
             "unit": "candidates/s",
             "n_gpus": n_gpus,

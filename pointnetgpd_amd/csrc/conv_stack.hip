@@ -242,6 +242,162 @@ __global__ __launch_bounds__(THREADS, 2) void conv_stack_bf16_kernel(ConvStackAr
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 path, software-pipelined inside each wave.
+// The plain kernel above serialises, per channel tile: LDS fragment reads -> 16 MFMAs -> max
+// reduction -> LDS merge, so one wave keeps the matrix pipe busy ~60 % of the time.  Here a wave
+// keeps two fragment sets and two accumulator sets: while the MFMAs of tile t run it (a) has the
+// fragments of tile t+1 in flight and (b) reduces the accumulators of tile t-1 on the VALU.
+// The chunk barrier sits in the MIDDLE of the second tile of each chunk: by then every wave holds
+// both tiles of the chunk in registers, so the same barrier that publishes chunk c+1 also frees
+// chunk c's buffer for the LDS-DMA of chunk c+2 (two buffers suffice).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_frags(bf16x8 (&bf)[8], const char* tile_base, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) bf[ks] = *(const bf16x8*)(tile_base + (ks * 64 + lane) * 16);
+}
+
+__device__ __forceinline__ f32x16 mfma_chain(const bf16x8 (&a)[8], const bf16x8 (&b)[8]) {
+    f32x16 acc = {0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[ks], acc, 0, 0, 0);
+    return acc;
+}
+
+template <int MT>
+__device__ __forceinline__ void reduce_tile(const f32x16 (&acc)[MT], float* s_red_wave, int nt, int r) {
+    float m = max16(acc[0]);
+#pragma unroll
+    for (int mt = 1; mt < MT; ++mt) m = __builtin_fmaxf(m, max16(acc[mt]));
+    m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+    float* p = s_red_wave + 32 * nt + r;        // lanes l and l+32 store the same value
+    *p = __builtin_fmaxf(*p, m);
+}
+
+template <int MT>
+__global__ __launch_bounds__(THREADS, 2) void conv_stack_bf16_pipelined_kernel(ConvStackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+
+    char* s_w3 = smem;
+    char* s_w2 = smem + BF_OFF_W2;
+    float4* s_w1 = (float4*)(smem + BF_OFF_W1);
+    float* s_b2 = (float*)(smem + BF_OFF_B2);
+    float* s_red = (float*)(smem + BF_OFF_RED);
+    const char* g_w3 = (const char*)a.w3p;
+
+    // prologue: W2 fragments and W3 chunks 0 and 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;
+        dma_piece((const char*)a.w2p + piece * 1024, s_w2 + piece * 1024, lane);
+        dma_piece(g_w3 + piece * 1024, s_w3 + piece * 1024, lane);
+        dma_piece(g_w3 + BF_CHUNK_BYTES + piece * 1024, s_w3 + BF_CHUNK_BYTES + piece * 1024, lane);
+    }
+    if (tid < C1) s_w1[tid] = fold_w1(a, b, tid);
+    if (tid < B2P_FLOATS) s_b2[tid] = a.b2p[tid];
+    for (int c = tid; c < WAVES * C3; c += THREADS) s_red[c] = -INFINITY;
+    __syncthreads();
+
+    float* s_red_wave = s_red + wave * C3;
+    const int pts_per_pass = WAVES * 32 * MT;
+    const int npass = (a.P + pts_per_pass - 1) / pts_per_pass;
+
+    bf16x8 bfA[8], bfB[8];
+    load_frags(bfA, s_w3, lane);                       // tile 0 of pass 0
+    bf16x8 a3[MT][8];
+
+    for (int pass = 0; pass < npass; ++pass) {
+        // ---- layer 1 (VALU) and layer 2 (transposed MFMA): A fragments of layer 3 ------------
+        {
+        float x0[MT], x1[MT], x2[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int pt = pass * pts_per_pass + (wave * MT + mt) * 32 + r;
+            pt = pt < a.P ? pt : a.P - 1;
+            load_point(a, b, pt, x0[mt], x1[mt], x2[mt]);
+        }
+        bf16x8 hb[MT][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 w = s_w1[16 * s + 8 * h + j];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float v = fmaf(w.x, x0[mt], fmaf(w.y, x1[mt], fmaf(w.z, x2[mt], w.w)));
+                    hb[mt][s][j] = (__bf16)__builtin_fmaxf(v, 0.f);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x16 acc[MT];
+            {
+                const f32x4* bq = (const f32x4*)(s_b2 + (t * 2 + h) * 16);
+                f32x16 binit;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = bq[q];
+                    binit[4 * q + 0] = v[0];
+                    binit[4 * q + 1] = v[1];
+                    binit[4 * q + 2] = v[2];
+                    binit[4 * q + 3] = v[3];
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = binit;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 wf = *(const bf16x8*)(s_w2 + ((t * 4 + s) * 64 + lane) * 16);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hb[mt][s], acc[mt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        a3[mt][2 * t + sp][j] = (__bf16)__builtin_fmaxf(acc[mt][8 * sp + j], 0.f);
+        }
+        }
+        // ---- layer 3, two tiles (one chunk) per iteration ------------------------------------
+        const bool last_pass = (pass == npass - 1);
+        f32x16 acc0[MT], acc1[MT];
+        for (int ck = 0; ck < BF_CHUNKS; ++ck) {
+            char* bufc = s_w3 + (ck & 1) * BF_CHUNK_BYTES;
+            const char* bufn = s_w3 + ((ck + 1) & 1) * BF_CHUNK_BYTES;
+            // tile 2ck: fragments already in bfA; fetch tile 2ck+1 of the same chunk
+            load_frags(bfB, bufc + BF_CHUNK_BYTES / 2, lane);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc0[mt] = mfma_chain(a3[mt], bfA);
+            if (ck > 0) reduce_tile<MT>(acc1, s_red_wave, 2 * ck - 1, r);
+            // tile 2ck+1: first chain, then the chunk barrier, then the rest
+            acc1[0] = mfma_chain(a3[0], bfB);
+            __syncthreads();                                   // chunk ck+1 landed; chunk ck's buffer is free
+            if (!(last_pass && ck >= BF_CHUNKS - 2)) {
+                const char* src = g_w3 + (size_t)((ck + 2) & (BF_CHUNKS - 1)) * BF_CHUNK_BYTES;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int piece = wave * 4 + i;
+                    dma_piece(src + piece * 1024, bufc + piece * 1024, lane);
+                }
+            }
+            if (!(last_pass && ck == BF_CHUNKS - 1)) load_frags(bfA, bufn, lane);   // tile 2ck+2
+#pragma unroll
+            for (int mt = 1; mt < MT; ++mt) acc1[mt] = mfma_chain(a3[mt], bfB);
+            reduce_tile<MT>(acc0, s_red_wave, 2 * ck, r);
+        }
+        reduce_tile<MT>(acc1, s_red_wave, 2 * BF_CHUNKS - 1, r);
+    }
+    __syncthreads();
+    write_pooled(a, b, s_red, tid);
+}
+
+// ------------------------------------------------------------------------------------------
 // exact-f32 MFMA path (v_mfma_f32_32x32x2_f32): every product is an f32 fma chain.
 // LDS: [0,16K) two W3 half-tile buffers (8 KiB) | [16K,48K) W2 fragments | conv1 table |
 //      conv2 bias | per-wave running maxima.
@@ -392,7 +548,10 @@ hipError_t launch_conv_stack_bf16(const ConvStackArgs& a, hipStream_t s) {
     hipError_t e = check_args(a);
     if (e != hipSuccess) return e;
     static_assert(BF_LDS_BYTES <= 80 * 1024, "two workgroups per CU");
-    auto kern = conv_stack_bf16_kernel<2>;
+    // points per pass = 128 * MT: take the MT with the least padding (ties: fewer passes).
+    // MT = 3 runs the plain kernel (the pipelined one would spill), MT = 2 the pipelined one.
+    const int pad2 = (a.P + 255) / 256 * 256, pad3 = (a.P + 383) / 384 * 384;
+    void (*kern)(ConvStackArgs) = pad3 <= pad2 ? conv_stack_bf16_kernel<3> : conv_stack_bf16_pipelined_kernel<2>;
     e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_BYTES);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(THREADS), BF_LDS_BYTES, s, a);

@@ -173,3 +173,42 @@ def test_standalone_submodules():
     assert (t.cpu() - ref_trans).abs().max().item() <= FP32_ATOL
     assert (t2.cpu() - ref_trans).abs().max().item() <= FP32_ATOL
     np.testing.assert_allclose(f.cpu().numpy(), ref_feat.numpy(), rtol=2e-5, atol=FP32_ATOL)
+
+
+def test_config3_full_size_p500_sharded_batch():
+    """B = 65,536 candidates of P = 500 points in bf16 (the largest batched configuration): finite,
+    normalised, and any contiguous shard scored alone gives bit-identical rows (what makes the
+    multi-GPU split of the batch exact)."""
+    B, P, seed = 65_536, 500, 43
+    m = hip_model(P, 2, seed, 0.02, "bf16", 1.7)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    hd, ow, hh = synth.GRIPPER_BOX
+    x = torch.rand((B, 3, P), generator=g, device="cuda")
+    x = x * torch.tensor([hd, ow, hh], device="cuda").view(1, 3, 1) + torch.tensor([0.0, -ow / 2, -hh / 2], device="cuda").view(1, 3, 1)
+    logp, trans = m(x)
+    assert torch.isfinite(logp).all() and torch.isfinite(trans).all()
+    assert torch.allclose(logp.exp().sum(1), torch.ones(B, device="cuda"), atol=1e-5)
+    for lo, hi in ((0, 8192), (57_344, 65_536), (30_000, 30_003)):
+        part, part_t = m(x[lo:hi].contiguous())
+        assert torch.equal(part, logp[lo:hi]) and torch.equal(part_t, trans[lo:hi])
+    oracle = po.build_cls(P, 2, synth.torch_state_dict(seed, 2, 0.02, 1.7))
+    idx = torch.tensor([0, 12_345, B - 1], device="cuda")
+    with torch.no_grad():
+        ref, _ = oracle(x[idx].cpu())
+    assert (logp[idx].cpu() - ref).abs().max().item() <= BF16_ATOL
+
+
+def test_p1000_full_view_variant():
+    """num_points = 1000 is what the reference's full-view scripts build (main_fullv.py:51,106)."""
+    P, seed = 1000, 45
+    sd = synth.torch_state_dict(seed, 2, 1.0, 1.7)
+    x = torch.from_numpy(synth.candidate_points(seed, 3, P, "normal"))
+    with torch.no_grad():
+        ref, _ = po.build_cls(P, 2, sd)(x)
+    for precision, tol in (("fp32", FP32_ATOL), ("bf16", BF16_ATOL)):
+        m = PointNetCls(P, 3, 2)
+        m.load_state_dict(sd)
+        m = m.cuda().eval()
+        m.precision = precision
+        logp, _ = m(x.cuda())
+        assert (logp.cpu() - ref).abs().max().item() <= tol
