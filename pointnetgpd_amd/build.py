@@ -25,6 +25,7 @@ LIB_SOURCES = [
     "conv_stack.hip",
     "fc.hip",
     "crop.hip",
+    "crop_grid.hip",
     "train.hip",
     "train_api.cpp",
 ]

@@ -304,9 +304,13 @@ int pngpd_profile_conv_stack(const pngpd_model* m, const float* x_dev, int layou
 // crop workspace: [G,12] f64 frames, then [G, Wp] u64 mask (frames region rounded up to 256 B)
 static size_t crop_frames_bytes(int G) { return ((size_t)G * 12 * sizeof(double) + 255) & ~(size_t)255; }
 
+static size_t crop_mask_bytes(int S, int G) {
+    return ((size_t)G * pngpd::crop_words_per_grasp(S) * sizeof(unsigned long long) + 255) & ~(size_t)255;
+}
+
 size_t pngpd_crop_workspace_bytes(int S, int G) {
     if (S < 1 || G < 1) return 0;
-    return crop_frames_bytes(G) + (size_t)G * pngpd::crop_words_per_grasp(S) * sizeof(unsigned long long);
+    return crop_frames_bytes(G) + crop_mask_bytes(S, G) + pngpd::crop_grid_bytes(S);
 }
 
 static int crop_ws_check(int S, int G, const void* ws, size_t bytes) {
@@ -327,7 +331,8 @@ int pngpd_crop_count(const float* scene_dev, int S, const double* grasps_dev, in
     pngpd::CropLimits L{limits[0], limits[1], limits[2], limits[3], limits[4], limits[5]};
     double* frames = (double*)workspace_dev;
     auto* mask = (unsigned long long*)((char*)workspace_dev + crop_frames_bytes(G));
-    HIP_TRY(pngpd::launch_crop_count(scene_dev, S, grasps_dev, G, L, frames, mask, cnt_dev,
+    void* grid_ws = (char*)workspace_dev + crop_frames_bytes(G) + crop_mask_bytes(S, G);
+    HIP_TRY(pngpd::launch_crop_count(scene_dev, S, grasps_dev, G, L, frames, mask, grid_ws, cnt_dev,
                                      (long long*)offsets_dev, (hipStream_t)stream));
     return PNGPD_OK;
 }

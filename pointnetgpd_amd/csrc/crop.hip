@@ -20,9 +20,8 @@
 //            round to float32 = the network input of main_test.py:74-76
 #include <hip/hip_runtime.h>
 
+#include "crop_math.h"
 #include "kernels.h"
-
-#pragma clang fp contract(off)
 
 namespace pngpd {
 
@@ -41,21 +40,6 @@ __global__ void crop_frames_kernel(const double* __restrict__ grasps, double* __
         f[3 + 3 * r + 1] = y / n;
         f[3 + 3 * r + 2] = z / n;
     }
-}
-
-struct PointD { double x, y, z; };
-
-__device__ __forceinline__ PointD to_gripper(const double* __restrict__ f, double px, double py, double pz) {
-    const double d0 = px - f[0], d1 = py - f[1], d2 = pz - f[2];
-    PointD q;
-    q.x = fma(f[5], d2, fma(f[4], d1, f[3] * d0));
-    q.y = fma(f[8], d2, fma(f[7], d1, f[6] * d0));
-    q.z = fma(f[11], d2, fma(f[10], d1, f[9] * d0));
-    return q;
-}
-
-__device__ __forceinline__ bool in_box(const PointD& q, const CropLimits& L) {
-    return (L.ylo < q.y) & (L.yhi > q.y) & (L.zhi > q.z) & (L.zlo < q.z) & (L.xhi > q.x) & (L.xlo < q.x);
 }
 
 __global__ __launch_bounds__(256) void crop_mask_kernel(const float* __restrict__ scene, int S,
@@ -282,13 +266,22 @@ int crop_words_per_grasp(int S) {
 }
 
 hipError_t launch_crop_count(const float* scene, int S, const double* grasps, int G, const CropLimits& L,
-                             double* frames, unsigned long long* mask, int* cnt, long long* offsets,
-                             hipStream_t s) {
-    if (!scene || !grasps || !frames || !mask || !cnt || !offsets || S < 1 || G < 1) return hipErrorInvalidValue;
+                             double* frames, unsigned long long* mask, void* grid_ws, int* cnt,
+                             long long* offsets, hipStream_t s) {
+    if (!scene || !grasps || !frames || !mask || !grid_ws || !cnt || !offsets || S < 1 || G < 1)
+        return hipErrorInvalidValue;
     const int Wp = crop_words_per_grasp(S);
     hipLaunchKernelGGL(crop_frames_kernel, dim3((G + 255) / 256), dim3(256), 0, s, grasps, frames, G);
-    dim3 grid((S + CROP_TILE - 1) / CROP_TILE, (G + CROP_GB - 1) / CROP_GB);
-    hipLaunchKernelGGL(crop_mask_kernel, grid, dim3(256), 0, s, scene, S, frames, G, L, mask, Wp);
+    // PNGPD_CROP_BRUTE=1 keeps the all-pairs pass (used by the tests to cross-check the culled one)
+    const char* brute_env = getenv("PNGPD_CROP_BRUTE");
+    const bool brute = brute_env && brute_env[0] == '1';
+    if (brute) {
+        dim3 grid((S + CROP_TILE - 1) / CROP_TILE, (G + CROP_GB - 1) / CROP_GB);
+        hipLaunchKernelGGL(crop_mask_kernel, grid, dim3(256), 0, s, scene, S, frames, G, L, mask, Wp);
+    } else {
+        hipError_t e = launch_crop_mask_grid(scene, S, (const double*)frames, G, L, mask, Wp, grid_ws, s);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(crop_count_kernel, dim3(G), dim3(256), 0, s, mask, Wp, cnt);
     hipLaunchKernelGGL(crop_offsets_kernel, dim3(1), dim3(256), 0, s, cnt, G, offsets);
     return hipGetLastError();

@@ -57,9 +57,17 @@ struct CropLimits { double ylo, yhi, zlo, zhi, xlo, xhi; };
 
 int crop_words_per_grasp(int S);             // 64-bit mask words per grasp (tile padded)
 
+// uniform grid over the scene for the culled crop
+constexpr int GRID_MAX_DIM = 64;
+constexpr int GRID_CELLS = GRID_MAX_DIM * GRID_MAX_DIM * GRID_MAX_DIM;
+struct GridParams { double origin[3]; double inv_cell; int dim[3]; int pad; };
+size_t crop_grid_bytes(int S);
+hipError_t launch_crop_mask_grid(const float* scene, int S, const double* frames, int G, const CropLimits& L,
+                                 unsigned long long* mask, int Wp, void* grid_ws, hipStream_t s);
+
 hipError_t launch_crop_count(const float* scene, int S, const double* grasps, int G, const CropLimits& L,
-                             double* frames, unsigned long long* mask, int* cnt, long long* offsets,
-                             hipStream_t s);
+                             double* frames, unsigned long long* mask, void* grid_ws, int* cnt,
+                             long long* offsets, hipStream_t s);
 hipError_t launch_crop_emit(const float* scene, int S, int G, const double* frames,
                             const unsigned long long* mask, const long long* offsets, int* idx,
                             long long capacity, double* pts_g, hipStream_t s);

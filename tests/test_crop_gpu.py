@@ -207,3 +207,32 @@ def test_online_pipeline_ranks_good_grasps():
     res_all = hc2.collect_pc(grasps, scene, LIMITS, return_points=False)
     pts_all, _ = hc2.subsample(res_all, P, repeat=3, seed=5)
     assert torch.equal(pts_slice, pts_all[30:60])
+
+
+@pytest.mark.parametrize("S,G,cube", [(300_000, 200, 0.4), (5_000, 50, 0.05), (2_000, 10, 3.0)])
+def test_grid_culled_pass_equals_all_pairs_pass(S, G, cube, monkeypatch):
+    """The spatially culled mask pass and the brute-force all-pairs pass give identical crops
+    (dense scene, a scene smaller than one gripper, and a sparse scene much larger than the grid)."""
+    seed = 97 + G
+    scene = torch.from_numpy(synth.scene_points(seed, S, cube)).cuda()
+    grasps = synth.random_grasps(seed, G, cube, min(0.03, cube / 4))
+    monkeypatch.setenv("PNGPD_CROP_BRUTE", "1")
+    brute = hc.collect_pc(grasps, scene, LIMITS)
+    monkeypatch.setenv("PNGPD_CROP_BRUTE", "0")
+    culled = hc.collect_pc(grasps, scene, LIMITS)
+    assert torch.equal(brute.counts, culled.counts)
+    assert torch.equal(brute.indices, culled.indices)
+    assert torch.equal(brute.points_g, culled.points_g)
+    if cube < 1.0:
+        assert int(culled.counts.sum()) > 0
+
+
+def test_grid_culling_with_degenerate_scenes():
+    pts = np.tile(np.array([[0.1, 0.1, 0.1]], dtype=np.float32), (500, 1))         # all points identical
+    g = np.zeros((2, 5, 3))
+    g[:, 1:4] = np.eye(3)
+    g[0, 4] = [0.07, 0.1, 0.1]      # point lies 3 cm in front of the palm: inside
+    g[1, 4] = [0.5, 0.5, 0.5]       # far away: empty
+    res = hc.collect_pc(g, torch.from_numpy(pts).cuda(), LIMITS)
+    np.testing.assert_array_equal(res.counts.cpu().numpy(), [500, 0])
+    np.testing.assert_array_equal(res.indices.cpu().numpy(), np.arange(500))
