@@ -48,7 +48,7 @@ struct StackDev {
 };
 
 struct FcDev {
-    DevBuf w[3], b[3];
+    DevBuf w[3], b[3], wsplit[2];
     int n[3] = {0, 0, 0}, k[3] = {0, 0, 0};
 };
 
@@ -102,7 +102,7 @@ int load_stack(const float* const* t, int u_conv1, StackDev& d, std::vector<Pack
 }
 
 int load_fc(const float* const* t, int u_fc1, int n_last, FcDev& d,
-            std::vector<std::vector<float>>& keep, hipStream_t s) {
+            std::vector<std::vector<float>>& keep, std::vector<std::vector<uint16_t>>& keep16, hipStream_t s) {
     const int n[3] = {512, 256, n_last}, k[3] = {1024, 512, 256};
     for (int i = 0; i < 3; ++i) {
         keep.emplace_back();
@@ -113,6 +113,11 @@ int load_fc(const float* const* t, int u_fc1, int n_last, FcDev& d,
         if (rc) return rc;
         HIP_TRY(d.w[i].upload(W.data(), W.size() * 4, s));
         HIP_TRY(d.b[i].upload(b.data(), b.size() * 4, s));
+        if (i < 2) {
+            keep16.emplace_back();
+            pngpd::pack_fc_split(W, n[i], k[i], keep16.back());
+            HIP_TRY(d.wsplit[i].upload(keep16.back().data(), keep16.back().size() * 2, s));
+        }
         d.n[i] = n[i];
         d.k[i] = k[i];
     }
@@ -136,12 +141,19 @@ struct Workspace {
     }
 };
 
-int run_fc_chain(const FcDev& fc, const float* in, Workspace& ws, float* out, int B, int tail,
+int run_fc_chain(const FcDev& fc, const float* in, Workspace& ws, float* out, int B, int tail, int precision,
                  hipStream_t s) {
-    HIP_TRY(pngpd::launch_fc_f32(in, (const float*)fc.w[0].p, (const float*)fc.b[0].p, ws.h512, B,
-                                 fc.n[0], fc.k[0], 1, s));
-    HIP_TRY(pngpd::launch_fc_f32(ws.h512, (const float*)fc.w[1].p, (const float*)fc.b[1].p, ws.h256,
-                                 B, fc.n[1], fc.k[1], 1, s));
+    if (precision == PNGPD_BF16) {
+        // split-bf16 products: f32-grade results on the bf16 matrix pipe
+        HIP_TRY(pngpd::launch_fc_bf16x3(in, fc.wsplit[0].p, (const float*)fc.b[0].p, ws.h512, B, fc.n[0], fc.k[0], 1, s));
+        HIP_TRY(pngpd::launch_fc_bf16x3(ws.h512, fc.wsplit[1].p, (const float*)fc.b[1].p, ws.h256, B, fc.n[1], fc.k[1],
+                                        1, s));
+    } else {
+        HIP_TRY(pngpd::launch_fc_f32(in, (const float*)fc.w[0].p, (const float*)fc.b[0].p, ws.h512, B,
+                                     fc.n[0], fc.k[0], 1, s));
+        HIP_TRY(pngpd::launch_fc_f32(ws.h512, (const float*)fc.w[1].p, (const float*)fc.b[1].p, ws.h256,
+                                     B, fc.n[1], fc.k[1], 1, s));
+    }
     HIP_TRY(pngpd::launch_fc_tail(ws.h256, (const float*)fc.w[2].p, (const float*)fc.b[2].p, out, B,
                                   fc.n[2], fc.k[2], tail, s));
     return PNGPD_OK;
@@ -212,15 +224,17 @@ int pngpd_model_load(pngpd_model* m, const float* const* host_tensors, int n_slo
     keep_stacks.reserve(2);
     std::vector<std::vector<float>> keep_fc;
     keep_fc.reserve(12);
+    std::vector<std::vector<uint16_t>> keep16;
+    keep16.reserve(4);
     int rc;
     if (m->parts & PNGPD_PART_STN) {
         if ((rc = load_stack(host_tensors, PNGPD_U_STN_CONV1, m->stn, keep_stacks, s))) return rc;
-        if ((rc = load_fc(host_tensors, PNGPD_U_STN_FC1, 9, m->stn_fc, keep_fc, s))) return rc;
+        if ((rc = load_fc(host_tensors, PNGPD_U_STN_FC1, 9, m->stn_fc, keep_fc, keep16, s))) return rc;
     }
     if (m->parts & PNGPD_PART_TRUNK)
         if ((rc = load_stack(host_tensors, PNGPD_U_FEAT_CONV1, m->trunk, keep_stacks, s))) return rc;
     if (m->parts & PNGPD_PART_HEAD)
-        if ((rc = load_fc(host_tensors, PNGPD_U_FC1, m->k, m->head_fc, keep_fc, s))) return rc;
+        if ((rc = load_fc(host_tensors, PNGPD_U_FC1, m->k, m->head_fc, keep_fc, keep16, s))) return rc;
     HIP_TRY(hipStreamSynchronize(s));   // staging vectors die at return
     m->loaded = true;
     return PNGPD_OK;
@@ -258,7 +272,7 @@ int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, in
     // STN3d: conv stack (ReLU after the max), then the 1024-512-256-9 regressor + identity
     float* trans = trans_dev ? trans_dev : ws.trans;
     HIP_TRY(launch_stack(stack_args(m->stn, precision, x_dev, layout, B, P, nullptr, ws.pooled, 1), s));
-    int rc = run_fc_chain(m->stn_fc, ws.pooled, ws, trans, B, pngpd::FC_TAIL_ADD_IDENTITY, s);
+    int rc = run_fc_chain(m->stn_fc, ws.pooled, ws, trans, B, pngpd::FC_TAIL_ADD_IDENTITY, precision, s);
     if (rc) return rc;
     if (!(m->parts & PNGPD_PART_TRUNK)) return PNGPD_OK;
 
@@ -268,7 +282,7 @@ int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, in
     if (!(m->parts & PNGPD_PART_HEAD) || !logp_dev) return PNGPD_OK;
 
     // PointNetCls head + log_softmax
-    return run_fc_chain(m->head_fc, feat, ws, logp_dev, B, pngpd::FC_TAIL_LOG_SOFTMAX, s);
+    return run_fc_chain(m->head_fc, feat, ws, logp_dev, B, pngpd::FC_TAIL_LOG_SOFTMAX, precision, s);
 }
 
 int pngpd_profile_conv_stack(const pngpd_model* m, const float* x_dev, int layout, int B, int P,

@@ -40,6 +40,11 @@ hipError_t launch_conv_stack_f32(const ConvStackArgs& a, hipStream_t s);
 hipError_t launch_fc_f32(const float* X, const float* W, const float* b, float* Y, int M, int N,
                          int K, int relu, hipStream_t s);
 
+// Same layer with split-bf16 operands (3 bf16 MFMAs per product term); Wp from pack_fc_split.
+// N % 128 == 0, K % 32 == 0.
+hipError_t launch_fc_bf16x3(const float* X, const void* Wp, const float* b, float* Y, int M, int N, int K, int relu,
+                            hipStream_t s);
+
 enum { FC_TAIL_PLAIN = 0, FC_TAIL_ADD_IDENTITY = 1, FC_TAIL_LOG_SOFTMAX = 2 };
 // Y[M,N] = tail(X[M,K] * W[N,K]^T + b[N]) for tiny N (<= 16), K % 256 == 0.
 hipError_t launch_fc_tail(const float* X, const float* W, const float* b, float* Y, int M, int N,

@@ -32,6 +32,30 @@ uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
+static float bf16_to_f32(uint16_t v) {
+    uint32_t u = (uint32_t)v << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+void pack_fc_split(const std::vector<float>& Wf, int N, int K, std::vector<uint16_t>& out) {
+    const int ksteps = K / 16;
+    out.resize((size_t)N * K * 2);
+    for (int nt = 0; nt < N / 32; ++nt)
+        for (int ks = 0; ks < ksteps; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 32 * nt + (l & 31), k = 16 * ks + 8 * (l >> 5) + j;
+                    const float w = Wf[(size_t)n * K + k];
+                    const uint16_t hi = f32_to_bf16_rne(w);
+                    const uint16_t lo = f32_to_bf16_rne(w - bf16_to_f32(hi));
+                    const size_t base = (((size_t)nt * ksteps + ks) * 2) * 512 + (size_t)l * 8 + j;
+                    out[base] = hi;
+                    out[base + 512] = lo;
+                }
+}
+
 void pack_stack(const std::vector<float>& W1f, const std::vector<float>& b1f,
                 const std::vector<float>& W2f, const std::vector<float>& b2f,
                 const std::vector<float>& W3f, const std::vector<float>& b3f, PackedStack& out) {

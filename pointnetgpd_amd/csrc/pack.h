@@ -29,6 +29,11 @@ struct PackedStack {
     std::vector<float> w3_f32;     // [nt32][q16][lane64][e4]
 };
 
+// Split-bf16 image of an FC weight matrix Wf [N,K] (N % 32 == 0, K % 16 == 0):
+// out[nt][ks][plane][lane][j], plane 0 = bf16(w), plane 1 = bf16(w - plane0), as the B operand
+// fragments of v_mfma_f32_32x32x16_bf16 (n = 32nt + lane%32, k = 16ks + 8(lane/32) + j).
+void pack_fc_split(const std::vector<float>& Wf, int N, int K, std::vector<uint16_t>& out);
+
 // W1f [64,3], W2f [128,64], W3f [1024,128]: BN-folded, row-major [out,in].
 void pack_stack(const std::vector<float>& W1f, const std::vector<float>& b1f,
                 const std::vector<float>& W2f, const std::vector<float>& b2f,
