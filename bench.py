@@ -262,6 +262,15 @@ def main():
     flop_launch = float(B) * P * FLOP_PER_POINT_STACK
     achieved = flop_launch / (ms.value * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.precision]
+    # HBM bytes per launch of that kernel come from PMC passes (FETCH_SIZE / WRITE_SIZE, corrected for
+    # gfx950) that cannot run inside this process; the committed measurement is reported when it is
+    # for this exact configuration, else null.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_conv_stack_traffic.json")
+    if os.path.exists(tpath):
+        t = json.load(open(tpath))
+        if t["config"] == {"B": B, "P": P, "precision": args.precision}:
+            traffic = t["hbm_bytes_per_launch"]
 
     if rank == 0:
         total = float(n_gpus) * B * args.steps
@@ -283,7 +292,7 @@ def main():
                        "batch_per_gpu": B, "points": P, "classes": k, "parallelism": f"dp{n_gpus}",
                        "whole_net_tflops": round(total / elapsed * flop_per_candidate(P, k) / 1e12, 2)},
             "roofline": {"bound": "mfma", "kernel": f"conv_stack_{args.precision}", "achieved": round(achieved, 2),
-                         "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                         "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel_ms": round(ms.value, 4), "flop_per_launch": flop_launch},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
