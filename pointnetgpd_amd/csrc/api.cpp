@@ -44,7 +44,7 @@ struct DevBuf {
 };
 
 struct StackDev {
-    DevBuf w1tab, b2p, b3, w2_bf16, w3_bf16, w2_f32, w3_f32;
+    DevBuf w1tab, b2p, b2, b3, w2_bf16, w3_bf16, w2_f32, w3_f32;
 };
 
 struct FcDev {
@@ -96,6 +96,7 @@ int load_stack(const float* const* t, int u_conv1, StackDev& d, std::vector<Pack
     HIP_TRY(d.b3.upload(p.b3.data(), p.b3.size() * 4, s));
     HIP_TRY(d.w2_bf16.upload(p.w2_bf16.data(), p.w2_bf16.size() * 2, s));
     HIP_TRY(d.w3_bf16.upload(p.w3_bf16.data(), p.w3_bf16.size() * 2, s));
+    HIP_TRY(d.b2.upload(p.b2.data(), p.b2.size() * 4, s));
     HIP_TRY(d.w2_f32.upload(p.w2_f32.data(), p.w2_f32.size() * 4, s));
     HIP_TRY(d.w3_f32.upload(p.w3_f32.data(), p.w3_f32.size() * 4, s));
     return PNGPD_OK;
@@ -169,7 +170,7 @@ pngpd::ConvStackArgs stack_args(const StackDev& d, int precision, const float* x
     a.w1tab = (const float4*)d.w1tab.p;
     a.trans = trans;
     a.w2p = precision == PNGPD_BF16 ? d.w2_bf16.p : d.w2_f32.p;
-    a.b2p = (const float*)d.b2p.p;
+    a.b2p = (const float*)(precision == PNGPD_BF16 ? d.b2.p : d.b2p.p);
     a.w3p = precision == PNGPD_BF16 ? d.w3_bf16.p : d.w3_f32.p;
     a.b3 = (const float*)d.b3.p;
     a.pooled = pooled;

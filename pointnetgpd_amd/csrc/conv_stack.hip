@@ -5,20 +5,21 @@
 // which is conv1->bn->relu->conv2->bn->relu->conv3->bn(->relu)->MaxPool1d(num_points) of
 // STN3d.forward (model/pointnet.py:30-34) and PointNetfeat.forward (model/pointnet.py:138-147)
 // with eval-mode BatchNorm folded into W/b.  The [B,1024,P] activation of the reference never
-// exists: each wave keeps a tile of points in registers from the input coordinates to the
-// per-channel maximum.
+// exists: a tile of points goes from its input coordinates to a per-channel maximum on chip.
 //
-// Work split (one workgroup = one candidate, 4 waves):
-//   * a pass covers 128*MT points; each wave owns MT tiles of 32 points;
-//   * layer 1 (K = 3) runs on the VALU, straight into the MFMA B-operand layout of layer 2;
-//   * layer 2 is computed TRANSPOSED, X[ch2][point] = W2^T-fragments * h1-fragments, so that the
-//     accumulator (point on the lane, channel in the register) is, after ReLU, directly the A
-//     operand of layer 3 (no LDS round trip, no cross-lane traffic);
-//   * layer 3 computes Z[point][ch3]: channel on the lane, points in the registers, so the
-//     max over points is a per-lane register reduction; W3 streams through LDS by LDS-DMA in
-//     fragment order (double buffered, one barrier per chunk) and is shared by the 4 waves;
-//   * per-wave running maxima live in LDS, merged and written once per candidate.
+// Common to both precisions:
+//   * layer 1 (K = 3) runs on the VALU, straight into the MFMA B-operand layout of layer 2, with
+//     the candidate's 3x3 input transform folded into the 64x3 weight table;
+//   * layer 2 is computed TRANSPOSED, X[ch2][point] = W2-fragments * h1-fragments, so that the
+//     accumulator (point on the lane, channels in the registers) is, after ReLU, directly the A
+//     operand of layer 3: no transposition through LDS, no cross-lane traffic.  The k order this
+//     implies for layer 3 is baked into the packed W3 image (pack.cpp);
+//   * layer 3 has the channel on the lane and points in the registers, so the max over points
+//     is a per-lane register reduction.
 // Points beyond P are clamped to point P-1: duplicates cannot change a maximum.
+//
+// bf16 path: weight-stationary persistent kernel on v_mfma_f32_16x16x32_bf16 (below).
+// f32 path:  one workgroup per candidate, W3 streamed through LDS, v_mfma_f32_32x32x2_f32.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -105,296 +106,175 @@ __device__ __forceinline__ void write_pooled(const ConvStackArgs& a, int b, cons
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 MFMA path (v_mfma_f32_32x32x16_bf16, f32 accumulate).
-// LDS: [0,32K) two W3 chunk buffers (2 ch3-tiles = 16 KiB each) | [32K,48K) W2 fragments |
-//      [48K,49K) conv1 table | [49K,49.5K) conv2 bias | [49.5K,65.5K) per-wave running maxima.
+// bf16 path: weight-stationary, persistent, v_mfma_f32_16x16x32_bf16 (f32 accumulate).
+//
+// One workgroup of 8 waves per CU walks over candidates b = blockIdx.x, +gridDim.x, ...
+// Wave w keeps the layer-3 B fragments of channels [128w, 128w+128) in 128 VGPRs for the whole
+// kernel (8 channel tiles of 16 x 4 k-steps of 32): W3 is read from memory once per workgroup,
+// and since a wave sees every point of a candidate for its channels the per-channel running
+// maximum is a register - no LDS merge, no cross-wave reduction.
+// What moves through LDS is the layer-3 A operand.  Points are handled in tiles of 16 and
+// batches of 16 tiles: wave w computes layers 1-2 of tiles 2w, 2w+1 of the NEXT batch and stores
+// their A fragments (2 x 4 KiB) into the other half of a double buffer; every wave then
+// multiplies every tile of the current batch with its own channels.  The produce step of wave w
+// sits in front of tile 2w of the consume loop, so the two waves of a SIMD (w and w+4) are never
+// both away from the matrix pipe.  One barrier per batch (256 points); the first batch of the
+// next candidate is produced during the last batch of the current one.
+//
+// Lane l = (c = l%16, q = l/16).  The transposed layer-2 accumulator register i of row tile T
+// holds channel 16T + 4q + i of point c, so the registers of tiles 2ks and 2ks+1 are the 8
+// k slots of layer-3 step ks.  This shape is used instead of 32x32x16 because the chip holds a
+// higher clock on it under sustained load (same cycles per flop, ~12 % more flop/s).
+//
+// LDS: [0,128K) two batches of A fragments | [128K,144K) W2 fragments | conv2 bias |
+//      per-wave conv1 tables (trans folded in; private to a wave, so no workgroup barrier).
 // ------------------------------------------------------------------------------------------
-constexpr int BF_CHUNK_BYTES = 16384;
-constexpr int BF_CHUNKS = 16;
-constexpr int BF_OFF_W2 = 2 * BF_CHUNK_BYTES;
-constexpr int BF_OFF_W1 = BF_OFF_W2 + (int)W2P_BF16_BYTES;
-constexpr int BF_OFF_B2 = BF_OFF_W1 + C1 * 16;
-constexpr int BF_OFF_RED = BF_OFF_B2 + B2P_FLOATS * 4;
-constexpr int BF_LDS_BYTES = BF_OFF_RED + WAVES * C3 * 4;
+constexpr int WS_WAVES = 8;
+constexpr int WS_THREADS = WS_WAVES * 64;
+constexpr int W16_TILE_BYTES = 4096;                       // [ks4][lane64][16 B]
+constexpr int W16_BATCH_TILES = 2 * WS_WAVES;
+constexpr int WS_BATCH_BYTES = W16_BATCH_TILES * W16_TILE_BYTES;
+constexpr int WS_OFF_W2 = 2 * WS_BATCH_BYTES;
+constexpr int WS_OFF_B2 = WS_OFF_W2 + (int)W2P_BF16_BYTES;
+constexpr int WS_OFF_W1 = WS_OFF_B2 + C2 * 4;
+constexpr int WS_LDS_BYTES = WS_OFF_W1 + WS_WAVES * C1 * 16;
+typedef f32x4 f32x4v;
 
-template <int MT>
-__global__ __launch_bounds__(THREADS, 2) void conv_stack_bf16_kernel(ConvStackArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.x;
-
-    char* s_w3 = smem;
-    char* s_w2 = smem + BF_OFF_W2;
-    float4* s_w1 = (float4*)(smem + BF_OFF_W1);
-    float* s_b2 = (float*)(smem + BF_OFF_B2);
-    float* s_red = (float*)(smem + BF_OFF_RED);
-    const char* g_w3 = (const char*)a.w3p;
-
-    // prologue: W2 fragments and W3 chunk 0 by LDS-DMA, small tables by ordinary stores
+__device__ __forceinline__ void produce_tiles(const ConvStackArgs& a, int b, int tile0, float4* s_w1w,
+                                             const char* s_w2, const float* s_b2, char* dst, int lane) {
+    const int c = lane & 15, q = lane >> 4;
+    s_w1w[lane] = fold_w1(a, b, lane);
+    float x0[2], x1[2], x2[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave * 4 + i;
-        dma_piece((const char*)a.w2p + piece * 1024, s_w2 + piece * 1024, lane);
-        dma_piece(g_w3 + piece * 1024, s_w3 + piece * 1024, lane);
+    for (int u = 0; u < 2; ++u) {
+        int pt = (tile0 + u) * 16 + c;
+        pt = pt < a.P ? pt : a.P - 1;
+        load_point(a, b, pt, x0[u], x1[u], x2[u]);
     }
-    if (tid < C1) s_w1[tid] = fold_w1(a, b, tid);
-    if (tid < B2P_FLOATS) s_b2[tid] = a.b2p[tid];
-    for (int c = tid; c < WAVES * C3; c += THREADS) s_red[c] = -INFINITY;
-    __syncthreads();
-
-    float* s_red_wave = s_red + wave * C3;
-    const int pts_per_pass = WAVES * 32 * MT;
-    const int npass = (a.P + pts_per_pass - 1) / pts_per_pass;
-
-    for (int pass = 0; pass < npass; ++pass) {
-        // ---- layer 1 on the VALU, written as the B fragments of layer 2 ---------------------
-        float x0[MT], x1[MT], x2[MT];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bf16x8 hb[2][2];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            int pt = pass * pts_per_pass + (wave * MT + mt) * 32 + r;
-            pt = pt < a.P ? pt : a.P - 1;
-            load_point(a, b, pt, x0[mt], x1[mt], x2[mt]);
-        }
-        bf16x8 hb[MT][4];
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float4 w = s_w1[16 * s + 8 * h + j];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    float v = fmaf(w.x, x0[mt], fmaf(w.y, x1[mt], fmaf(w.z, x2[mt], w.w)));
-                    hb[mt][s][j] = (__bf16)__builtin_fmaxf(v, 0.f);
-                }
-            }
-        }
-        // ---- layer 2, transposed: X[ch2][pt]; ReLU + pack = A fragments of layer 3 -----------
-        bf16x8 a3[MT][8];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x16 acc[MT];
-            {
-                const f32x4* bq = (const f32x4*)(s_b2 + (t * 2 + h) * 16);
-                f32x16 binit;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = bq[q];
-                    binit[4 * q + 0] = v[0];
-                    binit[4 * q + 1] = v[1];
-                    binit[4 * q + 2] = v[2];
-                    binit[4 * q + 3] = v[3];
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = binit;
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 wf = *(const bf16x8*)(s_w2 + ((t * 4 + s) * 64 + lane) * 16);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hb[mt][s], acc[mt], 0, 0, 0);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        a3[mt][2 * t + sp][j] = (__bf16)__builtin_fmaxf(acc[mt][8 * sp + j], 0.f);
-        }
-        // ---- layer 3 + max over points; W3 streamed in 16 chunks of 2 channel tiles ----------
-        const bool last_pass = (pass == npass - 1);
-#pragma unroll 2
-        for (int ck = 0; ck < BF_CHUNKS; ++ck) {
-            if (!(last_pass && ck == BF_CHUNKS - 1)) {
-                const int nxt = (ck + 1) & (BF_CHUNKS - 1);
-                const char* src = g_w3 + (size_t)nxt * BF_CHUNK_BYTES;
-                char* dst = s_w3 + ((ck + 1) & 1) * BF_CHUNK_BYTES;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int piece = wave * 4 + i;
-                    dma_piece(src + piece * 1024, dst + piece * 1024, lane);
-                }
-            }
-            const char* buf = s_w3 + (ck & 1) * BF_CHUNK_BYTES;
+        for (int j = 0; j < 8; ++j) {
+            const float4 w = s_w1w[32 * s + 8 * q + j];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                bf16x8 bf[8];
+                const float v = fmaf(w.x, x0[u], fmaf(w.y, x1[u], fmaf(w.z, x2[u], w.w)));
+                hb[u][s][j] = (__bf16)__builtin_fmaxf(v, 0.f);
+            }
+        }
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    bf[ks] = *(const bf16x8*)(buf + ((u * 8 + ks) * 64 + lane) * 16);
-                float m = -INFINITY;
+    for (int ks = 0; ks < 4; ++ks) {
+        f32x4v acc[2][2];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    f32x16 acc = {0};
+        for (int tt = 0; tt < 2; ++tt) {
+            const int T = 2 * ks + tt;
+            const f32x4v bias = *(const f32x4v*)(s_b2 + 16 * T + 4 * q);
+            acc[0][tt] = bias;
+            acc[1][tt] = bias;
 #pragma unroll
-                    for (int ks = 0; ks < 8; ++ks)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[mt][ks], bf[ks], acc, 0, 0, 0);
-                    m = __builtin_fmaxf(m, max16(acc));
-                }
-                merge_runmax(s_red_wave, 2 * ck + u, m, r, h);
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 wf = *(const bf16x8*)(s_w2 + ((T * 2 + s) * 64 + lane) * 16);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hb[u][s], acc[u][tt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (__bf16)__builtin_fmaxf(acc[u][j >> 2][j & 3], 0.f);
+            *(bf16x8*)(dst + u * W16_TILE_BYTES + (ks * 64 + lane) * 16) = f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+
+    char* s_a = smem;
+    char* s_w2 = smem + WS_OFF_W2;
+    float* s_b2 = (float*)(smem + WS_OFF_B2);
+    float4* s_w1w = (float4*)(smem + WS_OFF_W1) + wave * C1;
+
+    bf16x8 bw[8][4];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            bw[nt][ks] = *(const bf16x8*)((const char*)a.w3p + ((((wave * 8 + nt) * 4 + ks) * 64) + lane) * 16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = wave * 2 + i;
+        dma_piece((const char*)a.w2p + piece * 1024, s_w2 + piece * 1024, lane);
+    }
+    if (tid < C2) s_b2[tid] = a.b2p[tid];
+    __syncthreads();
+
+    const int ntiles = (a.P + 15) >> 4;
+    const int nbatch = (ntiles + W16_BATCH_TILES - 1) / W16_BATCH_TILES;
+    const int stride = gridDim.x;
+    const int ncand = (a.B - (int)blockIdx.x + stride - 1) / stride;
+
+    if (2 * wave < ntiles)
+        produce_tiles(a, blockIdx.x, 2 * wave, s_w1w, s_w2, s_b2, s_a + wave * 2 * W16_TILE_BYTES, lane);
+    __syncthreads();
+
+    int buf = 0;
+    for (int ci = 0; ci < ncand; ++ci) {
+        const int b = blockIdx.x + ci * stride;
+        float rm[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) rm[nt] = -INFINITY;
+        for (int bt = 0; bt < nbatch; ++bt, buf ^= 1) {
+            const int nt_b = min(W16_BATCH_TILES, ntiles - W16_BATCH_TILES * bt);
+            int nb = b, nbt = bt + 1;
+            bool have_next = true;
+            if (nbt == nbatch) {
+                nbt = 0;
+                nb = b + stride;
+                have_next = ci + 1 < ncand;
+            }
+            const int my_tile = nbt * W16_BATCH_TILES + 2 * wave;
+            have_next = have_next && my_tile < ntiles;
+            const int slot = 2 * wave < nt_b ? 2 * wave : 0;
+            const char* cur = s_a + buf * WS_BATCH_BYTES;
+            char* nxt = s_a + (buf ^ 1) * WS_BATCH_BYTES + wave * 2 * W16_TILE_BYTES;
+            for (int t = 0; t < nt_b; ++t) {
+                if (t == slot && have_next) produce_tiles(a, nb, my_tile, s_w1w, s_w2, s_b2, nxt, lane);
+                bf16x8 af[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    af[ks] = *(const bf16x8*)(cur + t * W16_TILE_BYTES + (ks * 64 + lane) * 16);
+                f32x4v acc[8];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bw[nt][ks], acc[nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt)
+                    rm[nt] = max3(rm[nt], max3(acc[nt][0], acc[nt][1], acc[nt][2]), acc[nt][3]);
             }
             __syncthreads();
         }
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            const int ch = wave * 128 + nt * 16 + c;
+            float m = __builtin_fmaxf(rm[nt], __shfl_xor(rm[nt], 16));
+            m = __builtin_fmaxf(m, __shfl_xor(m, 32)) + a.b3[ch];
+            if (a.relu_out) m = __builtin_fmaxf(m, 0.f);
+            if (q == 0) a.pooled[(size_t)b * C3 + ch] = m;
+        }
     }
-    write_pooled(a, b, s_red, tid);
-}
-
-// ------------------------------------------------------------------------------------------
-// bf16 path, software-pipelined inside each wave.
-// The plain kernel above serialises, per channel tile: LDS fragment reads -> 16 MFMAs -> max
-// reduction -> LDS merge, so one wave keeps the matrix pipe busy ~60 % of the time.  Here a wave
-// keeps two fragment sets and two accumulator sets: while the MFMAs of tile t run it (a) has the
-// fragments of tile t+1 in flight and (b) reduces the accumulators of tile t-1 on the VALU.
-// The chunk barrier sits in the MIDDLE of the second tile of each chunk: by then every wave holds
-// both tiles of the chunk in registers, so the same barrier that publishes chunk c+1 also frees
-// chunk c's buffer for the LDS-DMA of chunk c+2 (two buffers suffice).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_frags(bf16x8 (&bf)[8], const char* tile_base, int lane) {
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) bf[ks] = *(const bf16x8*)(tile_base + (ks * 64 + lane) * 16);
-}
-
-__device__ __forceinline__ f32x16 mfma_chain(const bf16x8 (&a)[8], const bf16x8 (&b)[8]) {
-    f32x16 acc = {0};
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[ks], acc, 0, 0, 0);
-    return acc;
-}
-
-template <int MT>
-__device__ __forceinline__ void reduce_tile(const f32x16 (&acc)[MT], float* s_red_wave, int nt, int r) {
-    float m = max16(acc[0]);
-#pragma unroll
-    for (int mt = 1; mt < MT; ++mt) m = __builtin_fmaxf(m, max16(acc[mt]));
-    m = __builtin_fmaxf(m, __shfl_xor(m, 32));
-    float* p = s_red_wave + 32 * nt + r;        // lanes l and l+32 store the same value
-    *p = __builtin_fmaxf(*p, m);
-}
-
-template <int MT>
-__global__ __launch_bounds__(THREADS, 2) void conv_stack_bf16_pipelined_kernel(ConvStackArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.x;
-
-    char* s_w3 = smem;
-    char* s_w2 = smem + BF_OFF_W2;
-    float4* s_w1 = (float4*)(smem + BF_OFF_W1);
-    float* s_b2 = (float*)(smem + BF_OFF_B2);
-    float* s_red = (float*)(smem + BF_OFF_RED);
-    const char* g_w3 = (const char*)a.w3p;
-
-    // prologue: W2 fragments and W3 chunks 0 and 1
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave * 4 + i;
-        dma_piece((const char*)a.w2p + piece * 1024, s_w2 + piece * 1024, lane);
-        dma_piece(g_w3 + piece * 1024, s_w3 + piece * 1024, lane);
-        dma_piece(g_w3 + BF_CHUNK_BYTES + piece * 1024, s_w3 + BF_CHUNK_BYTES + piece * 1024, lane);
-    }
-    if (tid < C1) s_w1[tid] = fold_w1(a, b, tid);
-    if (tid < B2P_FLOATS) s_b2[tid] = a.b2p[tid];
-    for (int c = tid; c < WAVES * C3; c += THREADS) s_red[c] = -INFINITY;
-    __syncthreads();
-
-    float* s_red_wave = s_red + wave * C3;
-    const int pts_per_pass = WAVES * 32 * MT;
-    const int npass = (a.P + pts_per_pass - 1) / pts_per_pass;
-
-    bf16x8 bfA[8], bfB[8];
-    load_frags(bfA, s_w3, lane);                       // tile 0 of pass 0
-    bf16x8 a3[MT][8];
-
-    for (int pass = 0; pass < npass; ++pass) {
-        // ---- layer 1 (VALU) and layer 2 (transposed MFMA): A fragments of layer 3 ------------
-        {
-        float x0[MT], x1[MT], x2[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            int pt = pass * pts_per_pass + (wave * MT + mt) * 32 + r;
-            pt = pt < a.P ? pt : a.P - 1;
-            load_point(a, b, pt, x0[mt], x1[mt], x2[mt]);
-        }
-        bf16x8 hb[MT][4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float4 w = s_w1[16 * s + 8 * h + j];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    float v = fmaf(w.x, x0[mt], fmaf(w.y, x1[mt], fmaf(w.z, x2[mt], w.w)));
-                    hb[mt][s][j] = (__bf16)__builtin_fmaxf(v, 0.f);
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x16 acc[MT];
-            {
-                const f32x4* bq = (const f32x4*)(s_b2 + (t * 2 + h) * 16);
-                f32x16 binit;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = bq[q];
-                    binit[4 * q + 0] = v[0];
-                    binit[4 * q + 1] = v[1];
-                    binit[4 * q + 2] = v[2];
-                    binit[4 * q + 3] = v[3];
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = binit;
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 wf = *(const bf16x8*)(s_w2 + ((t * 4 + s) * 64 + lane) * 16);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hb[mt][s], acc[mt], 0, 0, 0);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        a3[mt][2 * t + sp][j] = (__bf16)__builtin_fmaxf(acc[mt][8 * sp + j], 0.f);
-        }
-        }
-        // ---- layer 3, two tiles (one chunk) per iteration ------------------------------------
-        const bool last_pass = (pass == npass - 1);
-        f32x16 acc0[MT], acc1[MT];
-        for (int ck = 0; ck < BF_CHUNKS; ++ck) {
-            char* bufc = s_w3 + (ck & 1) * BF_CHUNK_BYTES;
-            const char* bufn = s_w3 + ((ck + 1) & 1) * BF_CHUNK_BYTES;
-            // tile 2ck: fragments already in bfA; fetch tile 2ck+1 of the same chunk
-            load_frags(bfB, bufc + BF_CHUNK_BYTES / 2, lane);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc0[mt] = mfma_chain(a3[mt], bfA);
-            if (ck > 0) reduce_tile<MT>(acc1, s_red_wave, 2 * ck - 1, r);
-            // tile 2ck+1: first chain, then the chunk barrier, then the rest
-            acc1[0] = mfma_chain(a3[0], bfB);
-            __syncthreads();                                   // chunk ck+1 landed; chunk ck's buffer is free
-            if (!(last_pass && ck >= BF_CHUNKS - 2)) {
-                const char* src = g_w3 + (size_t)((ck + 2) & (BF_CHUNKS - 1)) * BF_CHUNK_BYTES;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int piece = wave * 4 + i;
-                    dma_piece(src + piece * 1024, bufc + piece * 1024, lane);
-                }
-            }
-            if (!(last_pass && ck == BF_CHUNKS - 1)) load_frags(bfA, bufn, lane);   // tile 2ck+2
-#pragma unroll
-            for (int mt = 1; mt < MT; ++mt) acc1[mt] = mfma_chain(a3[mt], bfB);
-            reduce_tile<MT>(acc0, s_red_wave, 2 * ck, r);
-        }
-        reduce_tile<MT>(acc1, s_red_wave, 2 * BF_CHUNKS - 1, r);
-    }
-    __syncthreads();
-    write_pooled(a, b, s_red, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -547,14 +427,18 @@ static hipError_t check_args(const ConvStackArgs& a) {
 hipError_t launch_conv_stack_bf16(const ConvStackArgs& a, hipStream_t s) {
     hipError_t e = check_args(a);
     if (e != hipSuccess) return e;
-    static_assert(BF_LDS_BYTES <= 80 * 1024, "two workgroups per CU");
-    // points per pass = 128 * MT: take the MT with the least padding (ties: fewer passes).
-    // MT = 3 runs the plain kernel (the pipelined one would spill), MT = 2 the pipelined one.
-    const int pad2 = (a.P + 255) / 256 * 256, pad3 = (a.P + 383) / 384 * 384;
-    void (*kern)(ConvStackArgs) = pad3 <= pad2 ? conv_stack_bf16_kernel<3> : conv_stack_bf16_pipelined_kernel<2>;
-    e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_BYTES);
+    static_assert(WS_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+    int dev = 0, n_cu = 0;
+    e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3(THREADS), BF_LDS_BYTES, s, a);
+    e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    if (n_cu < 1) return hipErrorInvalidDevice;
+    e = hipFuncSetAttribute((const void*)conv_stack_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            WS_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    // persistent: one workgroup per CU, each strides over the candidates
+    hipLaunchKernelGGL(conv_stack_bf16_kernel, dim3(a.B < n_cu ? a.B : n_cu), dim3(WS_THREADS), WS_LDS_BYTES, s, a);
     return hipGetLastError();
 }
 

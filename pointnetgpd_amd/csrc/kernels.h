@@ -26,7 +26,7 @@ struct ConvStackArgs {
     const float4* w1tab;   // [64] {w0, w1, w2, bias}: BN-folded conv1
     const float* trans;    // [B,9] per-candidate 3x3 applied to the points first, or nullptr
     const void* w2p;       // packed BN-folded conv2 weights (bf16 or f32 image)
-    const float* b2p;      // [4][2][16] conv2 bias in accumulator-register order
+    const float* b2p;      // [128] conv2 bias: natural order (bf16), 32x32 accumulator order [4][2][16] (f32)
     const void* w3p;       // packed BN-folded conv3 weights (bf16 or f32 image)
     const float* b3;       // [1024] BN-folded conv3 bias
     float* pooled;         // [B,1024] max over points (+bias, optional ReLU)

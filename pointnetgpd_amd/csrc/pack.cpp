@@ -72,24 +72,26 @@ void pack_stack(const std::vector<float>& W1f, const std::vector<float>& b1f,
             for (int i = 0; i < 16; ++i) out.b2p[(t * 2 + h) * 16 + i] = b2f[32 * t + acc_row(i, h)];
     out.b3 = b3f;
 
-    // bf16 images: 32x32x16 fragments, 8 consecutive k per lane
+    // bf16 images for the 16x16x32 shape: lane l holds row/col l%16 and k = 8(l/16) + j.
+    // conv2 is computed transposed (A = weights): row tile T covers channels 16T..16T+15.
+    out.b2 = b2f;
     out.w2_bf16.resize((size_t)C2 * C1);
-    for (int t = 0; t < 4; ++t)
-        for (int s = 0; s < 4; ++s)
+    for (int T = 0; T < 8; ++T)
+        for (int s = 0; s < 2; ++s)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
-                    const int ch2 = 32 * t + (l & 31), k = 16 * s + 8 * (l >> 5) + j;
-                    out.w2_bf16[(((size_t)t * 4 + s) * 64 + l) * 8 + j] = f32_to_bf16_rne(W2f[(size_t)ch2 * C1 + k]);
+                    const int ch2 = 16 * T + (l & 15), k = 32 * s + 8 * (l >> 4) + j;
+                    out.w2_bf16[(((size_t)T * 2 + s) * 64 + l) * 8 + j] = f32_to_bf16_rne(W2f[(size_t)ch2 * C1 + k]);
                 }
-    // conv3's k slots follow the order in which conv2's accumulator registers are packed
+    // conv3's k slot (quarter q, elem j) of step ks is register j&3 of conv2 row tile 2ks + (j>>2)
     out.w3_bf16.resize((size_t)C3 * C2);
-    for (int nt = 0; nt < 32; ++nt)
-        for (int ks = 0; ks < 8; ++ks)
+    for (int NT = 0; NT < 64; ++NT)
+        for (int ks = 0; ks < 4; ++ks)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
-                    const int ch3 = 32 * nt + (l & 31);
-                    const int ch2 = 16 * ks + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
-                    out.w3_bf16[(((size_t)nt * 8 + ks) * 64 + l) * 8 + j] = f32_to_bf16_rne(W3f[(size_t)ch3 * C2 + ch2]);
+                    const int ch3 = 16 * NT + (l & 15);
+                    const int ch2 = 16 * (2 * ks + (j >> 2)) + 4 * (l >> 4) + (j & 3);
+                    out.w3_bf16[(((size_t)NT * 4 + ks) * 64 + l) * 8 + j] = f32_to_bf16_rne(W3f[(size_t)ch3 * C2 + ch2]);
                 }
 
     // f32 images: 32x32x2 fragments, one k per lane half; 4 consecutive steps per 16-byte read

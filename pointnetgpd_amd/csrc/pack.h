@@ -21,10 +21,11 @@ inline int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * 
 
 struct PackedStack {
     std::vector<float> w1tab;      // [64][4]  {w0,w1,w2,bias}
-    std::vector<float> b2p;        // [4][2][16]
+    std::vector<float> b2p;        // [4][2][16]  conv2 bias in 32x32 accumulator order (f32 path)
+    std::vector<float> b2;         // [128]       conv2 bias, natural order (bf16 path)
     std::vector<float> b3;         // [1024]
-    std::vector<uint16_t> w2_bf16; // [t4][s4][lane64][j8]
-    std::vector<uint16_t> w3_bf16; // [nt32][ks8][lane64][j8]
+    std::vector<uint16_t> w2_bf16; // [T8][s2][lane64][j8]    16x16x32 fragments
+    std::vector<uint16_t> w3_bf16; // [NT64][ks4][lane64][j8]
     std::vector<float> w2_f32;     // [t4][q8][lane64][e4]
     std::vector<float> w3_f32;     // [nt32][q16][lane64][e4]
 };

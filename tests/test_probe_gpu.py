@@ -70,7 +70,7 @@ def test_mfma_f32_layout(probe):
     np.testing.assert_array_equal(D.cpu().numpy(), A @ B)
 
 
-@pytest.mark.parametrize("name", ["probe_chain_bf16", "probe_chain_f32"])
+@pytest.mark.parametrize("name", ["probe_chain_f32"])
 def test_accumulator_as_operand(probe, name):
     import torch
     rng = np.random.default_rng(2)
@@ -81,4 +81,28 @@ def test_accumulator_as_operand(probe, name):
     assert getattr(probe, name)(_ptr(_dev(W)), _ptr(_dev(H)), _ptr(_dev(V)), _ptr(Z), _stream()) == 0
     torch.cuda.synchronize()
     X = np.maximum(W @ H, 0)          # small integers: exact in bf16 (|x| <= 144 < 256)
+    np.testing.assert_array_equal(Z.cpu().numpy(), X.T @ V)
+
+
+def test_mfma_bf16_16x16x32_layout(probe):
+    import torch
+    rng = np.random.default_rng(3)
+    A = _bf16_round(rng.integers(-4, 5, (16, 32)))
+    B = _bf16_round(rng.integers(-4, 5, (32, 16)))
+    D = torch.zeros(16, 16, device="cuda")
+    assert probe.probe_mfma_bf16_16(_ptr(_dev(A)), _ptr(_dev(B)), _ptr(D), _stream()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(D.cpu().numpy(), A @ B)
+
+
+def test_accumulator_as_operand_16x16x32(probe):
+    import torch
+    rng = np.random.default_rng(4)
+    W = rng.integers(-2, 3, (32, 32)).astype(np.float32)
+    H = rng.integers(-2, 3, (32, 16)).astype(np.float32)
+    V = rng.integers(-3, 4, (32, 16)).astype(np.float32)
+    Z = torch.zeros(16, 16, device="cuda")
+    assert probe.probe_chain_bf16_16(_ptr(_dev(W)), _ptr(_dev(H)), _ptr(_dev(V)), _ptr(Z), _stream()) == 0
+    torch.cuda.synchronize()
+    X = np.maximum(W @ H, 0)          # |x| <= 128: exact in bf16
     np.testing.assert_array_equal(Z.cpu().numpy(), X.T @ V)
