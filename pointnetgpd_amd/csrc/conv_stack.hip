@@ -133,65 +133,213 @@ constexpr int WS_WAVES = 8;
 constexpr int WS_THREADS = WS_WAVES * 64;
 constexpr int W16_TILE_BYTES = 4096;                       // [ks4][lane64][16 B]
 constexpr int W16_BATCH_TILES = 2 * WS_WAVES;
+#ifndef PNGPD_PRIO_PRODUCE
+#define PNGPD_PRIO_PRODUCE 3
+#define PNGPD_PRIO_CONSUME 0
+#endif
+#ifndef PNGPD_PRODUCER_WAVES
+#define PNGPD_PRODUCER_WAVES 8
+#endif
+constexpr int PRODUCER_WAVES = PNGPD_PRODUCER_WAVES;       // waves 0..PRODUCER_WAVES-1 produce
+constexpr int PRODUCE_STEPS = W16_BATCH_TILES / (2 * PRODUCER_WAVES);   // steps of 2 tiles per batch
 constexpr int WS_BATCH_BYTES = W16_BATCH_TILES * W16_TILE_BYTES;
 constexpr int WS_OFF_W2 = 2 * WS_BATCH_BYTES;
 constexpr int WS_OFF_B2 = WS_OFF_W2 + (int)W2P_BF16_BYTES;
-constexpr int WS_OFF_W1 = WS_OFF_B2 + C2 * 4;
+constexpr int WS_OFF_W1B = WS_OFF_B2 + C2 * 4;             // BN-folded conv1 table, shared
+constexpr int WS_OFF_W1 = WS_OFF_W1B + C1 * 16;            // per-wave copies with trans folded in
 constexpr int WS_LDS_BYTES = WS_OFF_W1 + WS_WAVES * C1 * 16;
 typedef f32x4 f32x4v;
 
-__device__ __forceinline__ void produce_tiles(const ConvStackArgs& a, int b, int tile0, float4* s_w1w,
-                                             const char* s_w2, const float* s_b2, char* dst, int lane) {
-    const int c = lane & 15, q = lane >> 4;
-    s_w1w[lane] = fold_w1(a, b, lane);
+// Orders this wave's own LDS accesses (a wave-private table is written, later read, by one wave).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// relu + bf16 pack of 8 accumulator values.  Rounding keeps the sign, so the clamp can follow the
+// rounding, where it is a packed int16 max against 0; the conversions are written two at a time
+// so that each is one v_cvt_pk_bf16_f32 (8 values: 4 conversions + 4 packed max).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ unsigned int relu_pack2(float a, float b) {
+    const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    s16x2 v = __builtin_bit_cast(s16x2, h);
+    v = __builtin_elementwise_max(v, (s16x2)(0));
+    return __builtin_bit_cast(unsigned int, v);
+}
+
+__device__ __forceinline__ bf16x8 relu_pack(const f32x4v& lo, const f32x4v& hi) {
+    u32x4 r;
+    r[0] = relu_pack2(lo[0], lo[1]);
+    r[1] = relu_pack2(lo[2], lo[3]);
+    r[2] = relu_pack2(hi[0], hi[1]);
+    r[3] = relu_pack2(hi[2], hi[3]);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// Coordinates of the two tiles of 16 points a wave produces; lane (c, q) holds point c of each.
+struct TilePoints {
     float x0[2], x1[2], x2[2];
+};
+
+__device__ __forceinline__ void load_tile_points(const ConvStackArgs& a, int b, int tile0, int c, TilePoints& p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         int pt = (tile0 + u) * 16 + c;
         pt = pt < a.P ? pt : a.P - 1;
-        load_point(a, b, pt, x0[u], x1[u], x2[u]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    bf16x8 hb[2][2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 w = s_w1w[32 * s + 8 * q + j];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float v = fmaf(w.x, x0[u], fmaf(w.y, x1[u], fmaf(w.z, x2[u], w.w)));
-                hb[u][s][j] = (__bf16)__builtin_fmaxf(v, 0.f);
-            }
-        }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        f32x4v acc[2][2];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int T = 2 * ks + tt;
-            const f32x4v bias = *(const f32x4v*)(s_b2 + 16 * T + 4 * q);
-            acc[0][tt] = bias;
-            acc[1][tt] = bias;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 wf = *(const bf16x8*)(s_w2 + ((T * 2 + s) * 64 + lane) * 16);
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    acc[u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hb[u][s], acc[u][tt], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            bf16x8 f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = (__bf16)__builtin_fmaxf(acc[u][j >> 2][j & 3], 0.f);
-            *(bf16x8*)(dst + u * W16_TILE_BYTES + (ks * 64 + lane) * 16) = f;
-        }
+        load_point(a, b, pt, p.x0[u], p.x1[u], p.x2[u]);
     }
 }
+
+// The wave's private conv1 table for candidate b (model/pointnet.py:138-142: the 3x3 input
+// transform is applied to the points before conv1; here it is applied to conv1's weights).
+__device__ __forceinline__ void fold_table(const ConvStackArgs& a, int b, const float4* s_w1base, float4* s_w1w,
+                                           int lane) {
+    float4 w = s_w1base[lane];
+    if (a.trans != nullptr) {
+        const float* T = a.trans + (size_t)b * 9;
+        float4 f;
+        f.x = w.x * T[0] + w.y * T[1] + w.z * T[2];
+        f.y = w.x * T[3] + w.y * T[4] + w.z * T[5];
+        f.z = w.x * T[6] + w.y * T[7] + w.z * T[8];
+        f.w = w.w;
+        w = f;
+    }
+    wave_lds_sync();
+    s_w1w[lane] = w;
+    wave_lds_sync();
+}
+
+// Layers 1-2 of two tiles of 16 points; their layer-3 A fragments go to dst, dst + 4 KiB.
+// The LDS reads are issued in groups ahead of their use (layer 2 double-buffers one k-step of
+// W2 fragments and bias), with fences so the scheduler keeps them there: left alone it emits
+// read -> wait -> two MFMAs thirty times over, and a produce step then costs thirty LDS latencies.
+struct L2Frags {
+    bf16x8 wf[2][2];     // [row tile of the pair][k-step of conv2]
+    f32x4v bias[2];
+};
+
+__device__ __forceinline__ void load_l2frags(L2Frags& f, int ks, const char* s_w2, const float* s_b2, int lane) {
+    const int q = lane >> 4;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int T = 2 * ks + tt;
+        f.bias[tt] = *(const f32x4v*)(s_b2 + 16 * T + 4 * q);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) f.wf[tt][s2] = *(const bf16x8*)(s_w2 + ((T * 2 + s2) * 64 + lane) * 16);
+    }
+}
+
+__device__ __forceinline__ void produce_tiles(const TilePoints& p, const float4* s_w1w, const char* s_w2,
+                                              const float* s_b2, char* dst, int lane) {
+    const int q = lane >> 4;
+    bf16x8 hb[2][2];
+    // the two tiles ride in the two halves of packed-f32 instructions
+    const f32x2 X0 = {p.x0[0], p.x0[1]}, X1 = {p.x1[0], p.x1[1]}, X2 = {p.x2[0], p.x2[1]};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4 r[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {          // 4 table rows per group of LDS reads
+            float4 w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = s_w1w[32 * s + 8 * q + 4 * g + j];
+            __builtin_amdgcn_sched_barrier(0);
+            f32x2 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 wx = {w[j].x, w[j].x}, wy = {w[j].y, w[j].y}, wz = {w[j].z, w[j].z}, wb = {w[j].w, w[j].w};
+                v[j] = __builtin_elementwise_fma(wx, X0, __builtin_elementwise_fma(wy, X1, __builtin_elementwise_fma(wz, X2, wb)));
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                r[u][2 * g] = relu_pack2(v[0][u], v[1][u]);
+                r[u][2 * g + 1] = relu_pack2(v[2][u], v[3][u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) hb[u][s] = __builtin_bit_cast(bf16x8, r[u]);
+    }
+    L2Frags fa, fb;
+    load_l2frags(fa, 0, s_w2, s_b2, lane);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        L2Frags& cur = (ks & 1) ? fb : fa;
+        L2Frags& nxt = (ks & 1) ? fa : fb;
+        if (ks + 1 < 4) load_l2frags(nxt, ks + 1, s_w2, s_b2, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4v acc[2][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                acc[u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.wf[tt][0], hb[u][0], cur.bias[tt], 0, 0, 0);
+                acc[u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.wf[tt][1], hb[u][1], acc[u][tt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            *(bf16x8*)(dst + u * W16_TILE_BYTES + (ks * 64 + lane) * 16) = relu_pack(acc[u][0], acc[u][1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void load_afrags(bf16x8 (&af)[4], const char* tile, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) af[ks] = *(const bf16x8*)(tile + (ks * 64 + lane) * 16);
+}
+
+// One tile of 16 points against the wave's 8 channel tiles.
+// Each channel tile is one chain of 4 MFMAs accumulating IN PLACE, issued back to back: on this
+// chip a dependent chain of v_mfma_f32_16x16x32_bf16 issues every 16.75 cycles, while the same
+// MFMAs interleaved over 8 accumulators take 24 cycles each (tools/ubench/mfma_stream.hip), so
+// the usual "interleave independent accumulators" ordering is the slow one here.
+// The max-reduction of a chain (2 v_max3) is issued after the FOLLOWING chain's four MFMAs, when
+// its result has long retired (no wait states) and never splits a chain; `carry` hands the last
+// chain of a tile over to the next call.
+__device__ __forceinline__ f32x4v mfma_chain4(const bf16x8 (&af)[4], const bf16x8 (&b)[4]) {
+    f32x4v z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], b[k], z, 0, 0, 0);
+    return z;
+}
+
+__device__ __forceinline__ void consume_tile(const bf16x8 (&af)[4], const bf16x8 (&bw)[8][4], f32x4v& carry,
+                                             float (&rm)[8]) {
+    f32x4v accA = carry, accB;
+#pragma unroll
+    for (int n = 0; n < 8; n += 2) {
+        accB = mfma_chain4(af, bw[n]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int pn = (n + 7) & 7;
+        rm[pn] = max3(rm[pn], max3(accA[0], accA[1], accA[2]), accA[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        accA = mfma_chain4(af, bw[n + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        rm[n] = max3(rm[n], max3(accB[0], accB[1], accB[2]), accB[3]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    carry = accA;
+}
+
+// Diagnostic build only (-DPNGPD_STAMPS, tools/diag): shader-clock stamps of workgroup 0 go to a
+// buffer of their own; no output value depends on them.  The product build compiles none of it.
+#ifdef PNGPD_STAMPS
+constexpr int STAMP_FIRST_BATCH = 6, STAMP_BATCHES = 6, STAMP_EVENTS = 5;
+__device__ unsigned long long g_stamps[WS_WAVES][STAMP_BATCHES * STAMP_EVENTS];
+__device__ unsigned long long g_stamp_clock[4];
+#define STAMP(g, ev)                                                                          \
+    do {                                                                                      \
+        if (blockIdx.x == 0 && lane == 0 && (g) >= STAMP_FIRST_BATCH &&                        \
+            (g) < STAMP_FIRST_BATCH + STAMP_BATCHES)                                          \
+            g_stamps[wave][((g)-STAMP_FIRST_BATCH) * STAMP_EVENTS + (ev)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define STAMP(g, ev)
+#endif
 
 __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -201,6 +349,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
     char* s_a = smem;
     char* s_w2 = smem + WS_OFF_W2;
     float* s_b2 = (float*)(smem + WS_OFF_B2);
+    float4* s_w1base = (float4*)(smem + WS_OFF_W1B);
     float4* s_w1w = (float4*)(smem + WS_OFF_W1) + wave * C1;
 
     bf16x8 bw[8][4];
@@ -215,6 +364,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
         dma_piece((const char*)a.w2p + piece * 1024, s_w2 + piece * 1024, lane);
     }
     if (tid < C2) s_b2[tid] = a.b2p[tid];
+    if (tid < C1) s_w1base[tid] = a.w1tab[tid];
     __syncthreads();
 
     const int ntiles = (a.P + 15) >> 4;
@@ -222,10 +372,41 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
     const int stride = gridDim.x;
     const int ncand = (a.B - (int)blockIdx.x + stride - 1) / stride;
 
-    if (2 * wave < ntiles)
-        produce_tiles(a, blockIdx.x, 2 * wave, s_w1w, s_w2, s_b2, s_a + wave * 2 * W16_TILE_BYTES, lane);
+    // Produce cursor: the (candidate, batch, half) this wave produces next.  Its points are
+    // loaded one step ahead and its conv1 table is folded when the candidate changes, so
+    // neither latency sits in front of a produce step.
+    const bool producer = wave < PRODUCER_WAVES;
+    int pb = blockIdx.x, pbt = 0, phalf = 0;
+    const int first_tile = 2 * PRODUCE_STEPS * wave;       // of this wave, within a batch
+    bool ptile = producer && first_tile < ntiles;
+    TilePoints px;
+    if (producer) fold_table(a, pb, s_w1base, s_w1w, lane);
+    if (ptile) load_tile_points(a, pb, first_tile, c, px);
+    auto produce_step = [&](char* batch_base) {
+        if (ptile) produce_tiles(px, s_w1w, s_w2, s_b2, batch_base + (first_tile + 2 * phalf) * W16_TILE_BYTES, lane);
+        if (++phalf == PRODUCE_STEPS) {
+            phalf = 0;
+            if (++pbt == nbatch) {
+                pbt = 0;
+                pb += stride;
+                if (pb < a.B) fold_table(a, pb, s_w1base, s_w1w, lane);
+            }
+        }
+        const int tile0 = pbt * W16_BATCH_TILES + first_tile + 2 * phalf;
+        ptile = pb < a.B && tile0 < ntiles;
+        if (ptile) load_tile_points(a, pb, tile0, c, px);
+    };
+    if (producer)
+        for (int st = 0; st < PRODUCE_STEPS; ++st) produce_step(s_a);
     __syncthreads();
 
+#ifdef PNGPD_STAMPS
+    if (blockIdx.x == 0 && tid == 0) {
+        g_stamp_clock[0] = __builtin_amdgcn_s_memtime();
+        g_stamp_clock[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    int g = 0;
+#endif
     int buf = 0;
     for (int ci = 0; ci < ncand; ++ci) {
         const int b = blockIdx.x + ci * stride;
@@ -234,37 +415,57 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
         for (int nt = 0; nt < 8; ++nt) rm[nt] = -INFINITY;
         for (int bt = 0; bt < nbatch; ++bt, buf ^= 1) {
             const int nt_b = min(W16_BATCH_TILES, ntiles - W16_BATCH_TILES * bt);
-            int nb = b, nbt = bt + 1;
-            bool have_next = true;
-            if (nbt == nbatch) {
-                nbt = 0;
-                nb = b + stride;
-                have_next = ci + 1 < ncand;
-            }
-            const int my_tile = nbt * W16_BATCH_TILES + 2 * wave;
-            have_next = have_next && my_tile < ntiles;
-            const int slot = 2 * wave < nt_b ? 2 * wave : 0;
+            const int npairs = (nt_b + 1) >> 1;
+            // pair indices in front of which this wave's two produce steps sit
+            const int step0 = producer ? min(wave, npairs - 1) : -1;
+            const int step1 = producer && PRODUCE_STEPS > 1 ? min(wave + PRODUCER_WAVES, npairs - 1) : -1;
             const char* cur = s_a + buf * WS_BATCH_BYTES;
-            char* nxt = s_a + (buf ^ 1) * WS_BATCH_BYTES + wave * 2 * W16_TILE_BYTES;
-            for (int t = 0; t < nt_b; ++t) {
-                if (t == slot && have_next) produce_tiles(a, nb, my_tile, s_w1w, s_w2, s_b2, nxt, lane);
-                bf16x8 af[4];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    af[ks] = *(const bf16x8*)(cur + t * W16_TILE_BYTES + (ks * 64 + lane) * 16);
-                f32x4v acc[8];
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int nt = 0; nt < 8; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bw[nt][ks], acc[nt], 0, 0, 0);
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt)
-                    rm[nt] = max3(rm[nt], max3(acc[nt][0], acc[nt][1], acc[nt][2]), acc[nt][3]);
+            char* nxt = s_a + (buf ^ 1) * WS_BATCH_BYTES;
+            STAMP(g, 0);
+            // Software pipeline over the tiles of the batch: the A fragments of the next tile are
+            // in flight during the MFMAs of the current one (consume_tile overlaps the
+            // max-reductions with the MFMAs).
+            bf16x8 afA[4], afB[4];
+            load_afrags(afA, cur, lane);
+            f32x4v carry = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (int i = 0; i < (nt_b >> 1); ++i) {
+                if (i == step0 || i == step1) {
+                    STAMP(g, 1);
+                    __builtin_amdgcn_s_setprio(PNGPD_PRIO_PRODUCE);
+#ifndef PNGPD_ABLATE_PRODUCE
+                    if (i == step0) produce_step(nxt);
+                    if (i == step1) produce_step(nxt);
+#endif
+                    __builtin_amdgcn_s_setprio(PNGPD_PRIO_CONSUME);
+                    STAMP(g, 2);
+                }
+#ifdef PNGPD_ABLATE_HALF
+                if (wave >= 4) continue;
+#endif
+                // Each tile's MFMAs run while the next tile's fragments load into the other set.
+                // No branches around the loads: the compiler then tracks the LDS counter exactly.
+                load_afrags(afB, cur + (2 * i + 1) * W16_TILE_BYTES, lane);
+                consume_tile(afA, bw, carry, rm);
+                load_afrags(afA, cur + min(2 * i + 2, nt_b - 1) * W16_TILE_BYTES, lane);
+                consume_tile(afB, bw, carry, rm);
             }
+            if (nt_b & 1) {                       // odd tail: afA already holds tile nt_b-1
+                const int i = nt_b >> 1;
+                if (i == step0 || i == step1) {
+                    __builtin_amdgcn_s_setprio(PNGPD_PRIO_PRODUCE);
+                    if (i == step0) produce_step(nxt);
+                    if (i == step1) produce_step(nxt);
+                    __builtin_amdgcn_s_setprio(PNGPD_PRIO_CONSUME);
+                }
+                consume_tile(afA, bw, carry, rm);
+            }
+            rm[7] = max3(rm[7], max3(carry[0], carry[1], carry[2]), carry[3]);
+            STAMP(g, 3);
             __syncthreads();
+            STAMP(g, 4);
+#ifdef PNGPD_STAMPS
+            ++g;
+#endif
         }
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
@@ -275,7 +476,21 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
             if (q == 0) a.pooled[(size_t)b * C3 + ch] = m;
         }
     }
+#ifdef PNGPD_STAMPS
+    if (blockIdx.x == 0 && tid == 0) {
+        g_stamp_clock[2] = __builtin_amdgcn_s_memtime();
+        g_stamp_clock[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
+
+#ifdef PNGPD_STAMPS
+extern "C" int pngpd_debug_read_stamps(unsigned long long* stamps, unsigned long long* clock) {
+    hipError_t e = hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemcpyFromSymbol(clock, HIP_SYMBOL(g_stamp_clock), sizeof(g_stamp_clock));
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // exact-f32 MFMA path (v_mfma_f32_32x32x2_f32): every product is an f32 fma chain.

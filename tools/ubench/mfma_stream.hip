@@ -1,0 +1,207 @@
+// Lone-wave issue rate of a 32-MFMA stream shaped like the conv-stack consume loop
+// (v_mfma_f32_16x16x32_bf16, 4 A fragments x 32 B fragments, 8 accumulation chains).
+// One wave per SIMD; prints shader cycles per MFMA for several operand arrangements.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int V>
+__global__ __launch_bounds__(512) void k_stream(const bf16x8* wsrc, const bf16x8* asrc, float* out,
+                                                unsigned long long* cyc, int iters) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 bw[8][4];
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bw[n][k] = wsrc[(n * 4 + k) * 64 + lane];
+    bf16x8 af[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) af[k] = asrc[k * 64 + lane];
+    f32x4 acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rm = 0.f, rm2 = (float)lane, rm3 = 1.f, rm4 = 2.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if (V == 0) {           // accumulate in place, ks-major over all 8 chains
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[n][k], acc[n], 0, 0, 0);
+        } else if (V == 1) {    // weights as the A operand instead of B
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[n][k], af[k], acc[n], 0, 0, 0);
+        } else if (V == 2) {    // a single B fragment
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[0][0], acc[n], 0, 0, 0);
+        } else if (V == 3) {    // 4 chains at a time (two groups), as the product kernel
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[4 * g + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[4 * g + n][k], acc[4 * g + n], 0, 0, 0);
+        } else if (V == 4) {    // single chain of 32 dependent MFMAs
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[n][k], acc[0], 0, 0, 0);
+        } else if (V == 5) {    // chain-major: 4 dependent MFMAs per chain, 8 chains in turn
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[n][k], acc[n], 0, 0, 0);
+        } else if (V == 6) {    // two chains alternating
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    acc[n & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[n][k], acc[n & 1], 0, 0, 0);
+        } else if (V == 7) {    // four chains alternating
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    acc[n & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[n][k], acc[n & 3], 0, 0, 0);
+        } else if (V == 8) {    // chain-major with a fresh accumulator per chain (C = 0), max-reduced
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[n][k], z, 0, 0, 0);
+                acc[n] = z;
+            }
+        } else if (V == 14 || V == 15) {   // V8 + two VALU per chain: unrelated (14) / reading a chain that retired 8 chains ago (15)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 old = acc[n];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[n][k], z, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (V == 14) { rm2 = fmaxf(fmaxf(rm2, rm3), rm4); rm3 = fmaxf(fmaxf(rm3, rm2), rm4); }
+                if (V == 15) rm = fmaxf(fmaxf(rm, fmaxf(fmaxf(old[0], old[1]), old[2])), old[3]);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[n] = z;
+            }
+        } else if (V == 9) {    // chain-major, pairs of chains interleaved (distance 2)
+#pragma unroll
+            for (int n = 0; n < 8; n += 2)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[n][k], acc[n], 0, 0, 0);
+                    acc[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[n + 1][k], acc[n + 1], 0, 0, 0);
+                }
+        } else if (V >= 10 && V <= 13) {
+            // chain-major with the max-reduction of the previous chain (2 VALU) per chain
+            f32x4 a0 = acc[0], a1;
+#pragma unroll
+            for (int n = 0; n < 8; n += 2) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    f32x4& cur = half == 0 ? a1 : a0;
+                    f32x4& old = half == 0 ? a0 : a1;
+                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    if (V == 12) {
+                        z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bw[n + half][0], z, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        rm = fmaxf(fmaxf(rm, fmaxf(fmaxf(old[0], old[1]), old[2])), old[3]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 1; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[n + half][k], z, 0, 0, 0);
+                        cur = z;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[n + half][k], z, 0, 0, 0);
+                        cur = z;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (V == 10) rm = fmaxf(fmaxf(rm, fmaxf(fmaxf(old[0], old[1]), old[2])), old[3]);
+                        if (V == 13) { rm2 = fmaxf(fmaxf(rm2, rm3), rm4); rm3 = fmaxf(fmaxf(rm3, rm2), rm4); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (V == 11) rm = fmaxf(rm, a0[0] + a1[1]);
+            acc[0] = a0;
+            acc[1] = a1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) rm += acc[n][0] + acc[n][1] + acc[n][2] + acc[n][3];
+    rm += rm2 + rm3;
+    out[blockIdx.x * 256 + threadIdx.x] = rm;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int V>
+static void run(const char* name, const bf16x8* w, const bf16x8* a, float* out, unsigned long long* cyc, int blocks) {
+    const int iters = 4000;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_stream<V>, dim3(blocks), dim3(256), 0, 0, w, a, out, cyc, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h(blocks);
+        hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost);
+        double mean = 0;
+        for (auto v : h) mean += (double)v;
+        mean /= blocks;
+        const double flop = (double)blocks * 4 * iters * 32 * 16 * 16 * 32 * 2;
+        printf("%-28s rep %d: %.2f ticks/MFMA, %.3f ms, %.0f TFLOP/s\n", name, rep, mean / (iters * 32.0), ms,
+               flop / (ms * 1e-3) / 1e12);
+    }
+}
+
+int main() {
+    const int blocks = 256;
+    std::vector<unsigned short> hw(32 * 64 * 8), ha(4 * 64 * 8);
+    srand(1);
+    for (auto& v : hw) v = (unsigned short)(0x3c00 + (rand() & 0x3ff));   // random bf16 around 0.01..
+    for (auto& v : ha) v = (unsigned short)(0x3c00 + (rand() & 0x3ff));
+    bf16x8 *w, *a;
+    float* out;
+    unsigned long long* cyc;
+    hipMalloc(&w, hw.size() * 2);
+    hipMalloc(&a, ha.size() * 2);
+    hipMalloc(&out, blocks * 256 * 4);
+    hipMalloc(&cyc, blocks * 8);
+    hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(a, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
+    run<0>("8 chains, B = 32 fragments", w, a, out, cyc, blocks);
+    run<1>("weights as A operand", w, a, out, cyc, blocks);
+    run<2>("single B fragment", w, a, out, cyc, blocks);
+    run<3>("two groups of 4 chains", w, a, out, cyc, blocks);
+    run<4>("one dependent chain", w, a, out, cyc, blocks);
+    run<5>("chain-major, 8 x 4", w, a, out, cyc, blocks);
+    run<10>("chains + max3 of previous", w, a, out, cyc, blocks);
+    run<14>("chains + 2 unrelated VALU", w, a, out, cyc, blocks);
+    run<15>("chains + max3 of 8 chains ago", w, a, out, cyc, blocks);
+    run<12>("chains + max3 after 1st MFMA", w, a, out, cyc, blocks);
+    run<6>("two chains alternating", w, a, out, cyc, blocks);
+    run<7>("four chains alternating", w, a, out, cyc, blocks);
+    run<8>("chain-major, C = 0 starts", w, a, out, cyc, blocks);
+    run<9>("chain-major, pairs", w, a, out, cyc, blocks);
+    return 0;
+}
