@@ -94,6 +94,28 @@ def test_against_oracle_fresh_inputs(B, precision, tol):
     assert ok
 
 
+RAGGED = [(1, 1), (2, 15), (3, 16), (3, 17), (5, 255), (5, 256), (5, 257), (4, 513), (257, 48), (300, 300), (600, 33)]
+
+
+@pytest.mark.parametrize("B,P", RAGGED, ids=[f"B{b}_P{p}" for b, p in RAGGED])
+@pytest.mark.parametrize("precision,tol", [("fp32", FP32_ATOL), ("bf16", BF16_ATOL)])
+def test_ragged_sizes(B, P, precision, tol):
+    """Point counts around the 16-point tile and 256-point batch edges (padding = duplicates of the
+    last point) and candidate counts around the number of CUs (the bf16 kernel is persistent: one
+    workgroup per CU strides over the candidates)."""
+    k, seed = 2, 41
+    sd = synth.torch_state_dict(seed, k, 0.02)
+    oracle = po.build_cls(P, k, sd)
+    m = hip_model(P, k, seed, 0.02, precision)
+    x = torch.from_numpy(synth.candidate_points(seed + B + P, B, P, "gripper"))
+    with torch.no_grad():
+        ref_logp, ref_trans = oracle(x)
+    logp, trans = m(x.cuda())
+    err = (logp.cpu() - ref_logp).abs().max().item()
+    assert err <= tol, err
+    assert (trans.cpu() - ref_trans).abs().max().item() <= (tol if precision == "fp32" else 5e-2)
+
+
 def test_points_layout_is_bitwise_equivalent():
     m = hip_model(750, 2, 33, 1.0, "bf16", 1.7)
     x = torch.from_numpy(synth.candidate_points(33, 5, 750, "normal")).cuda()
