@@ -183,6 +183,39 @@ def train_workload(args, dev, rank, n_gpus, dist):
         }), flush=True)
 
 
+def voxel_workload(args, dev, rank, n_gpus, dist):
+    """Scene pre-processing in front of the crop: voxel down-sampling of a 1M-point scene at n=500."""
+    from pointnetgpd_amd import voxel as hv
+
+    S, n = args.scene_points, args.voxel_n
+    scene = torch.from_numpy(synth.scene_points(rank, S, 0.5)).to(dev)
+    for _ in range(args.warmup):
+        out = hv.get_voxel_fun(scene, n)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = hv.get_voxel_fun(scene, n)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    M = out.shape[0]
+    bitmap = n ** 3 // 8
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        print(json.dumps({
+            "metric": "scene points voxel-down-sampled/sec", "value": round(n_gpus * S * args.steps / elapsed, 1),
+            "unit": "points/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 points, f64 edges",
+            "data": "synthetic",
+            "config": {"workload": f"get_voxel_fun: {S} points, n={n}, {M} unique centres (includes the host read of the count)",
+                       "algorithmic_GBps": round((S * 12 + M * 12) / (ms * 1e-3) / 1e9, 2),
+                       "bitmap_GBps": round((S * 12 + M * 12 + 3 * bitmap) / (ms * 1e-3) / 1e9, 2)},
+        }), flush=True)
+
+
 SETTLE_STEPS = 50
 
 
@@ -196,12 +229,13 @@ def main():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="score", choices=["score", "online", "train"],
+    ap.add_argument("--workload", default="score", choices=["score", "online", "train", "voxel"],
                     help="score: headline batch scoring; online: 1M-point scene x 10k grasps crop+score; "
                          "train: training step, batch 256 per GPU")
     ap.add_argument("--train-batch", type=int, default=256)
     ap.add_argument("--scene-points", type=int, default=1_000_000)
     ap.add_argument("--grasps", type=int, default=10_000)
+    ap.add_argument("--voxel-n", type=int, default=500)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,8 +254,8 @@ def main():
     if n_gpus != args.gpus and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
-    if args.workload in ("online", "train"):
-        (online_workload if args.workload == "online" else train_workload)(args, dev, rank, n_gpus, dist)
+    if args.workload in ("online", "train", "voxel"):
+        {"online": online_workload, "train": train_workload, "voxel": voxel_workload}[args.workload](args, dev, rank, n_gpus, dist)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()

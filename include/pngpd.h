@@ -177,6 +177,21 @@ int pngpd_vote(const int64_t* pred_dev, const float* probs_dev, const uint8_t* v
                int repeat, int k, int32_t* label_dev, float* score_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Voxel down-sampling of the scene, the step in front of the crop:
+ *   get_voxel_fun(points_, n)             apps/kinect2grasp.py:145-150
+ *   VoxelGrid(points, n, n, n).compute()  apps/voxelgrid.py:115-160
+ * points_dev [S,3] float32 -> the unique float32 centres of the occupied voxels of an n x n x n
+ * grid over the point cloud's bounding box made cubic, in np.unique(axis=0) order (lexicographic),
+ * written to out_dev [capacity,3]; *count_dev = number of unique centres (rows beyond `capacity`
+ * are counted but not written).  Bin edges are float64 (np.linspace on float32 scalars under the
+ * numpy 1.x promotion rules the reference was written for), centres float32.
+ * n in [1, 1600].  Workspace: pngpd_voxel_workspace_bytes(n) bytes (n^3 / 8 + small).
+ * ------------------------------------------------------------------------------------------ */
+size_t pngpd_voxel_workspace_bytes(int n);
+int pngpd_voxel_unique(const float* points_dev, int S, int n, void* workspace_dev, size_t workspace_bytes,
+                       float* out_dev, int64_t capacity, int32_t* count_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Training step: main_1v.py:262-274 (model.train(); output,_ = model(data); nll_loss; backward;
  * Adam).  fp32 throughout, train-mode BatchNorm1d with torch defaults (batch statistics, biased
  * variance for normalisation, running stats updated with momentum 0.1 and the unbiased variance,

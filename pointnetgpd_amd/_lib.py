@@ -48,6 +48,8 @@ SIGNATURES = {
     "pngpd_crop_gather": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_void_p, c_uint64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pngpd_vote": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pngpd_voxel_workspace_bytes": (c_size_t, [c_int]),
+    "pngpd_voxel_unique": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_void_p]),
     "pngpd_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pngpd_train_forward": (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p), c_int, c_float, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -26,6 +26,7 @@ LIB_SOURCES = [
     "fc.hip",
     "crop.hip",
     "crop_grid.hip",
+    "voxel.hip",
     "train.hip",
     "train_api.cpp",
 ]

@@ -391,6 +391,26 @@ int pngpd_vote(const int64_t* pred_dev, const float* probs_dev, const uint8_t* v
     return PNGPD_OK;
 }
 
+size_t pngpd_voxel_workspace_bytes(int n) {
+    if (n < 1 || n > pngpd::VOXEL_MAX_N) return 0;
+    return pngpd::voxel_workspace_bytes(n);
+}
+
+int pngpd_voxel_unique(const float* points_dev, int S, int n, void* workspace_dev, size_t workspace_bytes,
+                       float* out_dev, int64_t capacity, int32_t* count_dev, void* stream) {
+    if (!points_dev || !workspace_dev || !out_dev || !count_dev)
+        return fail(PNGPD_ERR_INVALID, "pngpd_voxel_unique: NULL argument");
+    if (S < 1 || n < 1 || n > pngpd::VOXEL_MAX_N || capacity < 0)
+        return fail(PNGPD_ERR_SHAPE, "pngpd_voxel_unique: S=%d n=%d (1..%d) capacity=%lld", S, n, pngpd::VOXEL_MAX_N,
+                    (long long)capacity);
+    if (workspace_bytes < pngpd::voxel_workspace_bytes(n))
+        return fail(PNGPD_ERR_WORKSPACE, "pngpd_voxel_unique: workspace %zu < %zu bytes", workspace_bytes,
+                    pngpd::voxel_workspace_bytes(n));
+    HIP_TRY(pngpd::launch_voxel_unique(points_dev, S, n, workspace_dev, out_dev, (long long)capacity, count_dev,
+                                       (hipStream_t)stream));
+    return PNGPD_OK;
+}
+
 int pngpd_score(const float* logp_dev, int B, int k, float* probs_dev, int64_t* pred_dev, void* stream) {
     if (!logp_dev || !probs_dev || !pred_dev) return fail(PNGPD_ERR_INVALID, "pngpd_score: NULL argument");
     if (B < 1 || k < 1) return fail(PNGPD_ERR_SHAPE, "pngpd_score: B=%d k=%d", B, k);

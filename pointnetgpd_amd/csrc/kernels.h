@@ -83,6 +83,12 @@ hipError_t launch_crop_gather(const float* scene, const double* frames, const in
 hipError_t launch_vote(const long long* pred, const float* probs, const unsigned char* valid, int G, int R, int k,
                        int* label, float* score, hipStream_t s);
 
+// ---- voxel down-sampling (voxel.hip) ------------------------------------------------------------
+constexpr int VOXEL_MAX_N = 1600;            // n^3 voxel keys must fit 32 bits
+size_t voxel_workspace_bytes(int n);
+hipError_t launch_voxel_unique(const float* pts, int S, int n, void* ws, float* out, long long capacity, int* count,
+                               hipStream_t s);
+
 // ---- training step (train.hip) ---------------------------------------------------------------
 constexpr int TN_ROWS_PER_CHUNK = 2048;      // rows of one weight-gradient partial (multiple of 32)
 

@@ -1,0 +1,299 @@
+// Voxel down-sampling of a scene to the unique centres of its occupied voxels:
+//   get_voxel_fun(points, n)          apps/kinect2grasp.py:145-150
+//   VoxelGrid(points, n, n, n).compute()   apps/voxelgrid.py:115-160
+//
+// The reference builds n+1 bin edges per axis with np.linspace over the bounding box made cubic,
+// finds each point's bin with np.searchsorted(edges, x) - 1, looks up the float32 bin centres and
+// keeps np.unique(rows): the unique centre triples in lexicographic order.
+//
+// Here: a float32 min/max reduction, one small setup block that redoes the reference's scalar
+// arithmetic operation by operation (float32 box, float64 edges = i*step + start with two
+// roundings, float32 centres), then one pass over the points that sets a bit per occupied voxel,
+// and a popcount / scan / expand pass over the bitmap.  Ascending bit order is the lexicographic
+// order of the centres, so nothing is sorted.  Two voxels whose float32 centres coincide on an
+// axis are the same row to np.unique; each axis index is therefore first mapped to the lowest
+// index with the same float32 centre.
+// HBM-bound: S*12 bytes of points, n^3/8 bytes of bitmap written once and read twice.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace pngpd {
+
+namespace {
+
+constexpr int VX_THREADS = 256;
+constexpr int VX_RED_BLOCKS = 512;
+constexpr int VX_WORDS_PER_BLOCK = 1024;     // bitmap words per block of the count / emit passes
+
+struct VoxelParams {
+    double start[3], stop[3], step[3];
+    int n;
+    int pad;
+};
+
+struct VoxelWs {
+    VoxelParams* prm;
+    float* partial;          // [VX_RED_BLOCKS][6]
+    float* mid;              // [3][n] float32 bin centres
+    int* canon;              // [3][n] lowest index with the same float32 centre
+    unsigned int* blocksum;  // [nblocks + 1]
+    unsigned int* bitmap;    // [words]
+};
+
+__host__ __device__ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+inline size_t vx_words(int n) { return ((size_t)n * n * n + 31) / 32; }
+inline size_t vx_blocks(int n) { return (vx_words(n) + VX_WORDS_PER_BLOCK - 1) / VX_WORDS_PER_BLOCK; }
+
+VoxelWs carve(void* ws, int n) {
+    char* p = (char*)ws;
+    VoxelWs w;
+    w.prm = (VoxelParams*)p;
+    p += align256(sizeof(VoxelParams));
+    w.partial = (float*)p;
+    p += align256((size_t)VX_RED_BLOCKS * 6 * 4);
+    w.mid = (float*)p;
+    p += align256((size_t)3 * n * 4);
+    w.canon = (int*)p;
+    p += align256((size_t)3 * n * 4);
+    w.blocksum = (unsigned int*)p;
+    p += align256((vx_blocks(n) + 1) * 4);
+    w.bitmap = (unsigned int*)p;
+    return w;
+}
+
+__global__ __launch_bounds__(VX_THREADS) void k_vox_minmax(const float* pts, int S, float* partial) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (long long i = blockIdx.x * (long long)VX_THREADS + threadIdx.x; i < S; i += (long long)gridDim.x * VX_THREADS) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = pts[i * 3 + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+    }
+    __shared__ float s[VX_THREADS / 64][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+        }
+        if (lane == 0) {
+            s[wave][a] = lo[a];
+            s[wave][3 + a] = hi[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s[0][threadIdx.x];
+        for (int w = 1; w < VX_THREADS / 64; ++w) v = threadIdx.x < 3 ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
+        partial[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+// Bin edge i of np.linspace(start, stop, n + 1): arange * step, then + start, last one = stop.
+__device__ __forceinline__ double vox_edge(const VoxelParams& p, int a, int i) {
+    if (i >= p.n) return p.stop[a];
+    if (p.step[a] == 0.0) return p.start[a];
+    const double t = (double)i * p.step[a];
+    return t + p.start[a];
+}
+
+__global__ __launch_bounds__(VX_THREADS) void k_vox_setup(const float* partial, int nparts, int n, VoxelParams* prm,
+                                                          float* mid, int* canon) {
+    __shared__ float s_mm[6];
+    __shared__ VoxelParams s_p;
+    if (threadIdx.x < 6) {
+        float v = partial[threadIdx.x];
+        for (int b = 1; b < nparts; ++b)
+            v = threadIdx.x < 3 ? fminf(v, partial[b * 6 + threadIdx.x]) : fmaxf(v, partial[b * 6 + threadIdx.x]);
+        s_mm[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // float32, as numpy does on float32 points: the box is grown to a cube around itself
+        float d[3], m = -INFINITY;
+        for (int a = 0; a < 3; ++a) {
+            d[a] = s_mm[3 + a] - s_mm[a];
+            m = fmaxf(m, d[a]);
+        }
+        for (int a = 0; a < 3; ++a) {
+            const float margin = m - d[a];
+            const float half = margin / 2.0f;
+            const float lo = s_mm[a] - half, hi = s_mm[3 + a] + half;
+            // float64 from here on (np.linspace on two float32 scalars and a Python float)
+            s_p.start[a] = (double)lo;
+            s_p.stop[a] = (double)hi;
+            const double delta = (double)hi - (double)lo;
+            s_p.step[a] = delta / (double)n;
+        }
+        s_p.n = n;
+        s_p.pad = 0;
+        *prm = s_p;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 3 * n; t += VX_THREADS) {
+        const int a = t / n, i = t - a * n;
+        const double e0 = vox_edge(s_p, a, i), e1 = vox_edge(s_p, a, i + 1);
+        mid[t] = (float)((e1 + e0) / 2.0);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 3 * n; t += VX_THREADS) {
+        const int a = t / n;
+        int i = t - a * n;
+        const float v = mid[t];
+        while (i > 0 && mid[a * n + i - 1] == v) --i;      // centres are non-decreasing along an axis
+        canon[t] = i;
+    }
+}
+
+// np.clip(np.searchsorted(edges, x) - 1, 0, n): searchsorted (side 'left') counts the edges < x.
+__device__ __forceinline__ int vox_bin(const VoxelParams& p, int a, float xf) {
+    const double x = (double)xf;
+    const int n = p.n;
+    if (p.step[a] == 0.0) return 0;
+    double g = (x - p.start[a]) / p.step[a];
+    int c = g < 0.0 ? 0 : (g > (double)n ? n : (int)g);      // first guess of the count, then exact
+    while (c <= n && vox_edge(p, a, c) < x) ++c;
+    while (c > 0 && !(vox_edge(p, a, c - 1) < x)) --c;
+    int idx = c - 1;
+    idx = idx < 0 ? 0 : idx;
+    return idx > n - 1 ? n - 1 : idx;   // x <= stop = the last edge, so the reference never exceeds n-1 either
+}
+
+__global__ __launch_bounds__(VX_THREADS) void k_vox_mark(const float* pts, int S, const VoxelParams* prm,
+                                                         const int* canon, unsigned int* bitmap) {
+    __shared__ VoxelParams s_p;
+    if (threadIdx.x == 0) s_p = *prm;
+    __syncthreads();
+    const int n = s_p.n;
+    for (long long i = blockIdx.x * (long long)VX_THREADS + threadIdx.x; i < S; i += (long long)gridDim.x * VX_THREADS) {
+        const int ix = canon[vox_bin(s_p, 0, pts[i * 3 + 0])];
+        const int iy = canon[n + vox_bin(s_p, 1, pts[i * 3 + 1])];
+        const int iz = canon[2 * n + vox_bin(s_p, 2, pts[i * 3 + 2])];
+        const unsigned long long key = ((unsigned long long)ix * n + iy) * n + iz;
+        atomicOr(&bitmap[key >> 5], 1u << (key & 31));
+    }
+}
+
+__global__ __launch_bounds__(VX_THREADS) void k_vox_count(const unsigned int* bitmap, size_t words, unsigned int* blocksum) {
+    const size_t base = (size_t)blockIdx.x * VX_WORDS_PER_BLOCK;
+    unsigned int c = 0;
+    for (int j = threadIdx.x; j < VX_WORDS_PER_BLOCK; j += VX_THREADS)
+        if (base + j < words) c += __popc(bitmap[base + j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    __shared__ unsigned int s[VX_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int t = 0;
+        for (int w = 0; w < VX_THREADS / 64; ++w) t += s[w];
+        blocksum[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of blocksum[0..nb) in place; blocksum[nb] = total; *count = total
+__global__ __launch_bounds__(1024) void k_vox_scan(unsigned int* blocksum, int nb, int* count) {
+    __shared__ unsigned int s[1024];
+    __shared__ unsigned int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const unsigned int v = i < nb ? blocksum[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const unsigned int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nb) blocksum[i] = carry + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        blocksum[nb] = carry;
+        *count = (int)carry;
+    }
+}
+
+__global__ __launch_bounds__(VX_THREADS) void k_vox_emit(const unsigned int* bitmap, size_t words,
+                                                         const unsigned int* blocksum, const float* mid, int n,
+                                                         float* out, long long capacity) {
+    // each thread owns 4 consecutive words: ascending bit order is preserved
+    constexpr int WPT = VX_WORDS_PER_BLOCK / VX_THREADS;
+    const size_t base = (size_t)blockIdx.x * VX_WORDS_PER_BLOCK + (size_t)threadIdx.x * WPT;
+    unsigned int w[WPT], c = 0;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        w[j] = base + j < words ? bitmap[base + j] : 0u;
+        c += __popc(w[j]);
+    }
+    __shared__ unsigned int s[VX_THREADS];
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 1; off < VX_THREADS; off <<= 1) {
+        const unsigned int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    long long pos = (long long)blocksum[blockIdx.x] + s[threadIdx.x] - c;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        unsigned int bits = w[j];
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            const unsigned long long key = (unsigned long long)(base + j) * 32 + b;
+            const int iz = (int)(key % n);
+            const unsigned long long r = key / n;
+            const int iy = (int)(r % n), ix = (int)(r / n);
+            if (pos < capacity) {
+                out[pos * 3 + 0] = mid[ix];
+                out[pos * 3 + 1] = mid[n + iy];
+                out[pos * 3 + 2] = mid[2 * n + iz];
+            }
+            ++pos;
+        }
+    }
+}
+
+}  // namespace
+
+size_t voxel_workspace_bytes(int n) {
+    return align256(sizeof(VoxelParams)) + align256((size_t)VX_RED_BLOCKS * 6 * 4) + 2 * align256((size_t)3 * n * 4) +
+           align256((vx_blocks(n) + 1) * 4) + align256(vx_words(n) * 4);
+}
+
+hipError_t launch_voxel_unique(const float* pts, int S, int n, void* ws, float* out, long long capacity, int* count,
+                               hipStream_t s) {
+    const VoxelWs w = carve(ws, n);
+    const size_t words = vx_words(n);
+    const int nb = (int)vx_blocks(n);
+    hipError_t e = hipMemsetAsync(w.bitmap, 0, words * 4, s);
+    if (e != hipSuccess) return e;
+    int red_blocks = (S + VX_THREADS - 1) / VX_THREADS;
+    red_blocks = red_blocks < VX_RED_BLOCKS ? red_blocks : VX_RED_BLOCKS;
+    hipLaunchKernelGGL(k_vox_minmax, dim3(red_blocks), dim3(VX_THREADS), 0, s, pts, S, w.partial);
+    hipLaunchKernelGGL(k_vox_setup, dim3(1), dim3(VX_THREADS), 0, s, w.partial, red_blocks, n, w.prm, w.mid, w.canon);
+    int mark_blocks = (S + VX_THREADS - 1) / VX_THREADS;
+    mark_blocks = mark_blocks < 4096 ? mark_blocks : 4096;
+    hipLaunchKernelGGL(k_vox_mark, dim3(mark_blocks), dim3(VX_THREADS), 0, s, pts, S, w.prm, w.canon, w.bitmap);
+    hipLaunchKernelGGL(k_vox_count, dim3(nb), dim3(VX_THREADS), 0, s, w.bitmap, words, w.blocksum);
+    hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, s, w.blocksum, nb, count);
+    hipLaunchKernelGGL(k_vox_emit, dim3(nb), dim3(VX_THREADS), 0, s, w.bitmap, words, w.blocksum, w.mid, n, out, capacity);
+    return hipGetLastError();
+}
+
+}  // namespace pngpd

@@ -1,0 +1,82 @@
+"""GPU parity of pngpd_voxel_unique (through the C ABI) against the CPU restatement of
+get_voxel_fun (apps/kinect2grasp.py:145-150): the unique float32 voxel centres, bit-exact and in
+the same order.  The restatement itself is unpinned (the reference module needs numba)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import voxel_oracle as vo
+from pointnetgpd_amd import synth, voxel
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(pts, n):
+    got = voxel.get_voxel_fun(torch.from_numpy(pts).cuda(), n).cpu().numpy()
+    want = vo.get_voxel_fun(pts, n)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    np.testing.assert_array_equal(got, want)
+    return len(want)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 500])
+def test_random_cloud(n):
+    rng = np.random.default_rng(n)
+    pts = (rng.random((20000, 3)) * np.array([0.5, 0.3, 0.1]) + np.array([0.2, -0.4, 0.9])).astype(np.float32)
+    m = _check(pts, n)
+    assert 1 <= m <= 20000
+
+
+def test_points_on_bin_edges_and_corners():
+    # a lattice whose points sit exactly on the bin edges of the n=8 grid over [0, 1]^3
+    g = np.linspace(0, 1, 9, dtype=np.float32)
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    assert _check(pts, 8) == 8 ** 3
+    _check(pts, 5)
+    _check(pts, 16)
+
+
+def test_degenerate_and_tiny_clouds():
+    _check(np.array([[0.3, -0.2, 1.5]] * 7, dtype=np.float32), 10)
+    _check(np.array([[0.0, 0.0, 0.0]], dtype=np.float32), 3)
+    _check(np.array([[0, 0, 0], [1, 0, 0]], dtype=np.float32), 4)            # flat in y, z: the box is still a cube
+
+
+def test_float32_centres_that_coincide_are_one_row():
+    # a 1e-4 wide cloud far from the origin: at n=1600 the bin width is below one float32 ulp of the
+    # coordinates, so neighbouring bins share a float32 centre and np.unique merges them
+    rng = np.random.default_rng(5)
+    pts = (rng.random((4000, 3)) * 1e-4 + 37.0).astype(np.float32)
+    m = _check(pts, 1600)
+    assert m < 4000
+
+
+def test_scene_size_and_idempotence():
+    pts = synth.scene_points(0, 1_000_000)
+    t = torch.from_numpy(pts).cuda()
+    v = voxel.get_voxel_fun(t, 500)
+    want = vo.get_voxel_fun(pts, 500)
+    np.testing.assert_array_equal(v.cpu().numpy(), want)
+    # the centres of a grid are fixed points of the same grid only if the box does not move; what
+    # always holds: a second pass cannot produce more rows than the first, and rows stay sorted
+    v2 = voxel.get_voxel_fun(v, 500)
+    assert v2.shape[0] <= v.shape[0]
+    a = v.cpu().numpy()
+    assert (np.lexsort((a[:, 2], a[:, 1], a[:, 0])) == np.arange(len(a))).all()
+
+
+def test_small_cloud_retry_loop():
+    rng = np.random.default_rng(9)
+    pts = rng.random((500, 3)).astype(np.float32) * 0.2
+    v = voxel.voxelize_scene(torch.from_numpy(pts).cuda(), 20)
+    assert v.shape[0] >= 500 - 15
+
+
+def test_rejects_bad_arguments():
+    t = torch.zeros(10, 3, device="cuda")
+    with pytest.raises(ValueError):
+        voxel.get_voxel_fun(t, 0)
+    with pytest.raises(ValueError):
+        voxel.get_voxel_fun(t, 1601)
+    with pytest.raises(RuntimeError):
+        voxel.get_voxel_fun(torch.zeros(10, 3), 4)

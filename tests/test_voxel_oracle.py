@@ -1,0 +1,53 @@
+"""CPU checks of the voxel down-sampling restatement (oracle/voxel_oracle.py) on cases whose answer
+can be written down by hand, and of its shortcut against the literal centre-table form."""
+import numpy as np
+
+from oracle import voxel_oracle as vo
+
+
+def test_unit_cube_two_bins():
+    pts = np.array([[0, 0, 0], [1, 1, 1], [0.2, 0.9, 0.4], [0.6, 0.1, 0.5]], dtype=np.float32)
+    got = vo.get_voxel_fun(pts, 2)
+    # bins [0,0.5], (0.5,1]; centres 0.25 / 0.75.  0.5 sits ON an edge: searchsorted 'left' puts it below.
+    want = np.array([[0.25, 0.25, 0.25], [0.25, 0.75, 0.25], [0.75, 0.25, 0.25], [0.75, 0.75, 0.75]], dtype=np.float32)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_box_is_made_cubic_around_itself():
+    pts = np.array([[0, 0, 0], [4, 2, 1]], dtype=np.float32)
+    _, seg, _ = vo.voxel_grid(pts, 4)
+    np.testing.assert_array_equal(seg[0], [0, 1, 2, 3, 4])
+    np.testing.assert_array_equal(seg[1], [-1, 0, 1, 2, 3])
+    np.testing.assert_array_equal(seg[2], [-1.5, -0.5, 0.5, 1.5, 2.5])
+    assert seg[0].dtype == np.float64
+
+
+def test_minimum_point_and_edge_points_go_to_the_lower_bin():
+    pts = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [4, 4, 4]], dtype=np.float32)
+    vn, _, _ = vo.voxel_grid(pts, 4)
+    ix = np.unravel_index(vn, (4, 4, 4))[0]
+    np.testing.assert_array_equal(ix, [0, 0, 1, 3])
+
+
+def test_shortcut_equals_full_table():
+    rng = np.random.default_rng(0)
+    pts = (rng.random((3000, 3)) * np.array([0.5, 0.3, 0.1]) + 0.7).astype(np.float32)
+    for n in (1, 2, 7, 31):
+        np.testing.assert_array_equal(vo.get_voxel_fun(pts, n), vo.get_voxel_fun_full_table(pts, n))
+
+
+def test_degenerate_single_point():
+    pts = np.array([[0.3, -0.2, 1.5]] * 5, dtype=np.float32)
+    got = vo.get_voxel_fun(pts, 8)
+    assert got.shape == (1, 3)
+    np.testing.assert_array_equal(got[0], pts[0])
+
+
+def test_output_is_sorted_unique_float32():
+    rng = np.random.default_rng(1)
+    pts = rng.normal(size=(5000, 3)).astype(np.float32)
+    got = vo.get_voxel_fun(pts, 50)
+    assert got.dtype == np.float32 and len(got) <= 5000
+    order = np.lexsort((got[:, 2], got[:, 1], got[:, 0]))
+    np.testing.assert_array_equal(order, np.arange(len(got)))
+    assert len(np.unique(got, axis=0)) == len(got)
