@@ -142,6 +142,18 @@ int pngpd_crop_count(const float* scene_dev, int S, const double* grasps_dev, in
                      const double* limits, void* workspace_dev, size_t workspace_bytes,
                      int32_t* cnt_dev, int64_t* offsets_dev, void* stream);
 
+/*
+ * Same crop for frames the caller has already built: the training-side collect_pc_
+ * (model/dataset.py:767-924) derives its frame from an 8-float grasp record and a 4x4 view
+ * transform and applies it WITHOUT re-normalising.  frames_dev float64 [G,12] = origin (bottom_,
+ * :825) followed by the rows of `matrix` (:835: approach_, binormal_, minor_normal_);
+ * pc_c2g = matrix (pc - bottom_) (:843) and the six plane tests (:870-880) are those of the
+ * online crop.  Same call order, workspace and outputs as pngpd_crop_count.
+ */
+int pngpd_crop_count_frames(const float* scene_dev, int S, const double* frames_dev, int G,
+                            const double* limits, void* workspace_dev, size_t workspace_bytes,
+                            int32_t* cnt_dev, int64_t* offsets_dev, void* stream);
+
 /* idx_dev int32 [idx_capacity]: for grasp g the ascending scene indices sit at
  * offsets[g] .. offsets[g+1]-1 (in_ind_, :413); entries at or beyond idx_capacity are dropped.
  * pts_g_dev (optional) float64 [idx_capacity,3]: the same points in the gripper frame
@@ -167,6 +179,20 @@ int pngpd_crop_gather(const float* scene_dev, int S, int G, const void* workspac
                       const int32_t* cnt_dev, int repeat, int P, int min_points,
                       const int32_t* sel_dev, uint64_t seed, int first_grasp_id,
                       float* pts_out_dev, int32_t* sel_out_dev, uint8_t* valid_dev, void* stream);
+
+/*
+ * The dataset's form of the same step (PointGraspOneViewDataset.__getitem__,
+ * model/dataset.py:1098-1111): one draw per grasp, output float32 [G,3,P] (the `.T` of :1106),
+ * without replacement only when cnt > P (:1104; cnt == P is drawn WITH replacement, unlike the
+ * online rule), grasps with fewer than min_points (min_point_limit = 50, :918) get
+ * valid_dev[g] = 0 and zeros (the dataset returns None for them).
+ */
+int pngpd_crop_gather_dataset(const float* scene_dev, int S, int G, const void* workspace_dev,
+                              size_t workspace_bytes, const int32_t* idx_dev,
+                              const int64_t* offsets_dev, const int32_t* cnt_dev, int P,
+                              int min_points, const int32_t* sel_dev, uint64_t seed,
+                              int first_grasp_id, float* pts_out_dev, int32_t* sel_out_dev,
+                              uint8_t* valid_dev, void* stream);
 
 /*
  * Repeat vote (apps/kinect2grasp.py:799-817): pred_dev int64 [G*repeat], probs_dev [G*repeat,k]

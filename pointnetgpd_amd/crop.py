@@ -148,13 +148,14 @@ def _mix64(z):
         return z ^ (z >> np.uint64(31))
 
 
-def draw_selection(seed: int, g: int, r: int, n: int, P: int) -> np.ndarray:
-    """The P positions the device draws for (grasp g, repeat r) when the grasp holds n points."""
+def draw_selection(seed: int, g: int, r: int, n: int, P: int, replace_when_equal: bool = False) -> np.ndarray:
+    """The P positions the device draws for (grasp g, repeat r) when the grasp holds n points.
+    replace_when_equal: the dataset's rule (n == P drawn with replacement, model/dataset.py:1104)."""
     with np.errstate(over="ignore"):
         inner = _mix64((np.uint64(g) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(r)) & _M)
         key = _mix64(np.uint64(seed & (2 ** 64 - 1)) ^ inner)
         i = np.arange(P, dtype=np.uint64)
-        if n < P:
+        if n < P + int(replace_when_equal):
             u = _mix64((key + i) & _M) >> np.uint64(32)
             return ((u * np.uint64(n)) >> np.uint64(32)).astype(np.int32)
         hb = 1

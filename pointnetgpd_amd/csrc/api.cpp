@@ -352,6 +352,22 @@ int pngpd_crop_count(const float* scene_dev, int S, const double* grasps_dev, in
     return PNGPD_OK;
 }
 
+int pngpd_crop_count_frames(const float* scene_dev, int S, const double* frames_dev, int G, const double* limits,
+                            void* workspace_dev, size_t workspace_bytes, int32_t* cnt_dev, int64_t* offsets_dev,
+                            void* stream) {
+    if (!scene_dev || !frames_dev || !limits || !cnt_dev || !offsets_dev)
+        return fail(PNGPD_ERR_INVALID, "pngpd_crop_count_frames: NULL argument");
+    int rc = crop_ws_check(S, G, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    pngpd::CropLimits L{limits[0], limits[1], limits[2], limits[3], limits[4], limits[5]};
+    double* frames = (double*)workspace_dev;
+    auto* mask = (unsigned long long*)((char*)workspace_dev + crop_frames_bytes(G));
+    void* grid_ws = (char*)workspace_dev + crop_frames_bytes(G) + crop_mask_bytes(S, G);
+    HIP_TRY(pngpd::launch_crop_count(scene_dev, S, frames_dev, G, L, frames, mask, grid_ws, cnt_dev,
+                                     (long long*)offsets_dev, (hipStream_t)stream, true));
+    return PNGPD_OK;
+}
+
 int pngpd_crop_emit(const float* scene_dev, int S, int G, const void* workspace_dev, size_t workspace_bytes,
                     const int64_t* offsets_dev, int32_t* idx_dev, int64_t idx_capacity, double* pts_g_dev,
                     void* stream) {
@@ -379,6 +395,21 @@ int pngpd_crop_gather(const float* scene_dev, int S, int G, const void* workspac
     HIP_TRY(pngpd::launch_crop_gather(scene_dev, (const double*)workspace_dev, idx_dev, (const long long*)offsets_dev,
                                       cnt_dev, G, repeat, P, min_points, sel_dev, seed, first_grasp_id, pts_out_dev, sel_out_dev,
                                       valid_dev, (hipStream_t)stream));
+    return PNGPD_OK;
+}
+
+int pngpd_crop_gather_dataset(const float* scene_dev, int S, int G, const void* workspace_dev, size_t workspace_bytes,
+                              const int32_t* idx_dev, const int64_t* offsets_dev, const int32_t* cnt_dev, int P,
+                              int min_points, const int32_t* sel_dev, uint64_t seed, int first_grasp_id,
+                              float* pts_out_dev, int32_t* sel_out_dev, uint8_t* valid_dev, void* stream) {
+    if (!scene_dev || !idx_dev || !offsets_dev || !cnt_dev || !pts_out_dev || !valid_dev)
+        return fail(PNGPD_ERR_INVALID, "pngpd_crop_gather_dataset: NULL argument");
+    if (P < 1 || min_points < 1) return fail(PNGPD_ERR_SHAPE, "pngpd_crop_gather_dataset: P=%d min_points=%d", P, min_points);
+    int rc = crop_ws_check(S, G, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    HIP_TRY(pngpd::launch_crop_gather(scene_dev, (const double*)workspace_dev, idx_dev, (const long long*)offsets_dev,
+                                      cnt_dev, G, 1, P, min_points, sel_dev, seed, first_grasp_id, pts_out_dev, sel_out_dev,
+                                      valid_dev, (hipStream_t)stream, 1, 1));
     return PNGPD_OK;
 }
 

@@ -175,9 +175,12 @@ __host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long 
 // i-th draw for (grasp g, repeat r) out of n cropped points, P draws in total.
 // n >= P: i -> a keyed 4-round Feistel permutation of [0, 4^hb) cycle-walked into [0, n): the P
 //         draws are distinct (sampling without replacement);  n < P: independent uniform draws.
-__host__ __device__ __forceinline__ int draw_selection(unsigned long long seed, int g, int r, int i, int n, int P) {
+// replace_when_equal: n == P is drawn WITH replacement (the dataset's `len > N` rule,
+// model/dataset.py:1104-1111) instead of without (the online `len >= N` rule, apps/kinect2grasp.py:756).
+__host__ __device__ __forceinline__ int draw_selection(unsigned long long seed, int g, int r, int i, int n, int P,
+                                                       int replace_when_equal = 0) {
     const unsigned long long key = mix64(seed ^ mix64((unsigned long long)g * 0x9E3779B97F4A7C15ull + (unsigned long long)r));
-    if (n < P) {
+    if (n < P + replace_when_equal) {
         const unsigned long long u = mix64(key + (unsigned long long)i) >> 32;
         return (int)((u * (unsigned long long)n) >> 32);
     }
@@ -207,7 +210,8 @@ __global__ __launch_bounds__(256) void crop_gather_kernel(const float* __restric
                                                           unsigned long long seed, int first_grasp_id,
                                                           float* __restrict__ pts_out,
                                                           int* __restrict__ sel_out,
-                                                          unsigned char* __restrict__ valid) {
+                                                          unsigned char* __restrict__ valid,
+                                                          int replace_when_equal, int channels_first) {
     const int g = blockIdx.x / R, r = blockIdx.x % R, tid = threadIdx.x;
     const int n = cnt[g];
     float* out = pts_out + (size_t)blockIdx.x * P * 3;
@@ -222,14 +226,20 @@ __global__ __launch_bounds__(256) void crop_gather_kernel(const float* __restric
     const double* f = frames + (size_t)g * 12;
     const long long base = offsets[g];
     for (int i = tid; i < P; i += 256) {
-        const int j = sel != nullptr ? sel[(size_t)blockIdx.x * P + i] : draw_selection(seed, first_grasp_id + g, r, i, n, P);
+        const int j = sel != nullptr ? sel[(size_t)blockIdx.x * P + i] : draw_selection(seed, first_grasp_id + g, r, i, n, P, replace_when_equal);
         if (sel_out != nullptr) sel_out[(size_t)blockIdx.x * P + i] = j;
         const int s = idx[base + j];
         const float* p = scene + (size_t)s * 3;
         const PointD q = to_gripper(f, (double)p[0], (double)p[1], (double)p[2]);
-        out[3 * i + 0] = (float)q.x;
-        out[3 * i + 1] = (float)q.y;
-        out[3 * i + 2] = (float)q.z;
+        if (channels_first) {        // [3,P]: grasp_pc[...].T of the dataset (model/dataset.py:1106)
+            out[i] = (float)q.x;
+            out[P + i] = (float)q.y;
+            out[2 * P + i] = (float)q.z;
+        } else {
+            out[3 * i + 0] = (float)q.x;
+            out[3 * i + 1] = (float)q.y;
+            out[3 * i + 2] = (float)q.z;
+        }
     }
 }
 
@@ -267,11 +277,16 @@ int crop_words_per_grasp(int S) {
 
 hipError_t launch_crop_count(const float* scene, int S, const double* grasps, int G, const CropLimits& L,
                              double* frames, unsigned long long* mask, void* grid_ws, int* cnt,
-                             long long* offsets, hipStream_t s) {
+                             long long* offsets, hipStream_t s, bool frames_given) {
     if (!scene || !grasps || !frames || !mask || !grid_ws || !cnt || !offsets || S < 1 || G < 1)
         return hipErrorInvalidValue;
     const int Wp = crop_words_per_grasp(S);
-    hipLaunchKernelGGL(crop_frames_kernel, dim3((G + 255) / 256), dim3(256), 0, s, grasps, frames, G);
+    if (frames_given) {   // `grasps` already is [G,12]: origin + the three matrix rows, used as they are
+        hipError_t e = hipMemcpyAsync(frames, grasps, (size_t)G * 12 * sizeof(double), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return e;
+    } else {
+        hipLaunchKernelGGL(crop_frames_kernel, dim3((G + 255) / 256), dim3(256), 0, s, grasps, frames, G);
+    }
     // PNGPD_CROP_BRUTE=1 keeps the all-pairs pass (used by the tests to cross-check the culled one)
     const char* brute_env = getenv("PNGPD_CROP_BRUTE");
     const bool brute = brute_env && brute_env[0] == '1';
@@ -299,11 +314,11 @@ hipError_t launch_crop_emit(const float* scene, int S, int G, const double* fram
 hipError_t launch_crop_gather(const float* scene, const double* frames, const int* idx, const long long* offsets,
                               const int* cnt, int G, int R, int P, int min_points, const int* sel,
                               unsigned long long seed, int first_grasp_id, float* pts_out, int* sel_out,
-                              unsigned char* valid, hipStream_t s) {
+                              unsigned char* valid, hipStream_t s, int replace_when_equal, int channels_first) {
     if (!scene || !frames || !idx || !offsets || !cnt || !pts_out || !valid || G < 1 || R < 1 || P < 1)
         return hipErrorInvalidValue;
     hipLaunchKernelGGL(crop_gather_kernel, dim3(G * R), dim3(256), 0, s, scene, frames, idx, offsets, cnt, R, P,
-                       min_points, sel, seed, first_grasp_id, pts_out, sel_out, valid);
+                       min_points, sel, seed, first_grasp_id, pts_out, sel_out, valid, replace_when_equal, channels_first);
     return hipGetLastError();
 }
 

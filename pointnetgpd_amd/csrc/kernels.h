@@ -72,14 +72,14 @@ hipError_t launch_crop_mask_grid(const float* scene, int S, const double* frames
 
 hipError_t launch_crop_count(const float* scene, int S, const double* grasps, int G, const CropLimits& L,
                              double* frames, unsigned long long* mask, void* grid_ws, int* cnt,
-                             long long* offsets, hipStream_t s);
+                             long long* offsets, hipStream_t s, bool frames_given = false);
 hipError_t launch_crop_emit(const float* scene, int S, int G, const double* frames,
                             const unsigned long long* mask, const long long* offsets, int* idx,
                             long long capacity, double* pts_g, hipStream_t s);
 hipError_t launch_crop_gather(const float* scene, const double* frames, const int* idx, const long long* offsets,
                               const int* cnt, int G, int R, int P, int min_points, const int* sel,
                               unsigned long long seed, int first_grasp_id, float* pts_out, int* sel_out,
-                              unsigned char* valid, hipStream_t s);
+                              unsigned char* valid, hipStream_t s, int replace_when_equal = 0, int channels_first = 0);
 hipError_t launch_vote(const long long* pred, const float* probs, const unsigned char* valid, int G, int R, int k,
                        int* label, float* score, hipStream_t s);
 

@@ -163,3 +163,30 @@ def random_grasps(seed: int, G: int, cube: float = 0.5, margin: float = 0.06) ->
     for r in range(3):
         g[:, 1 + r] = R[:, :, r] * lengths[:, r:r + 1]     # columns of R are the frame axes
     return g
+
+
+def dataset_view(seed: int, S: int, G: int, cube: float = 0.3):
+    """One synthetic (object, view) of the training-data crop: grasp records float64 [G,10]
+    (contact centre, closing axis (not unit), width, angle, level score, refine score; the layout
+    collect_pc_ and __getitem__ read, model/dataset.py:776-779, 1100), a rigid 4x4 transform, and the
+    view's cloud float32 [S,3], uniform in a cube around the transformed object."""
+    c = uniform(seed, "ds.center", (G, 3), 0.08, cube - 0.08).astype(np.float64)
+    axis = uniform(seed, "ds.axis", (G, 3), -1.0, 1.0).astype(np.float64) * 3.0
+    axis[0] = [0.0, 0.0, 2.0]                      # the degenerate branch of :798 (axis along z)
+    width = uniform(seed, "ds.width", (G,), 0.02, 0.08).astype(np.float64)
+    angle = uniform(seed, "ds.angle", (G,), -np.pi, np.pi).astype(np.float64)
+    level = np.floor(uniform(seed, "ds.level", (G,), 0.0, 5.0)).astype(np.float64) * 0.2
+    refine = uniform(seed, "ds.refine", (G,), 0.0, 1.0).astype(np.float64)
+    grasps = np.concatenate([c, axis, width[:, None], angle[:, None], level[:, None], refine[:, None]], axis=1)
+    q = uniform(seed, "ds.quat", (4,), -1.0, 1.0).astype(np.float64)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = uniform(seed, "ds.trans", (3,), -0.5, 0.5).astype(np.float64)
+    local = uniform(seed, "ds.cloud", (S, 3), 0.0, cube).astype(np.float64)
+    pc = (local @ R.T + T[:3, 3]).astype(np.float32)
+    return grasps, T, pc

@@ -1,0 +1,65 @@
+"""CPU checks of the training-data crop restatement (oracle/dataset_crop_oracle.py) on a case that
+can be verified by hand, and of the host-side frame / label helpers of the product mirror."""
+import numpy as np
+
+from oracle import crop_oracle as co
+from oracle import dataset_crop_oracle as do
+from pointnetgpd_amd import dataset_crop as dc
+from pointnetgpd_amd import synth
+
+
+def _hand_points():
+    return co.hand_points(0.06, 0.10, 0.01, 0.02)
+
+
+def test_axis_aligned_grasp_identity_transform():
+    # closing axis +y, angle 0: axis_x = (1,0,0) -> approach = +x, minor = y x x = -z ... the frame is
+    # (x, y, -z) up to sign, origin = centre - hand_depth * x.  Points are tested in that frame.
+    hp = _hand_points()
+    grasp = np.array([0.1, 0.0, 0.0, 0.0, 2.0, 0.0, 0.05, 0.0, 0.0, 0.0])
+    pc = np.array([[0.07, 0.0, 0.0],      # 3 cm in front of the bottom: inside
+                   [0.03, 0.0, 0.0],      # behind the bottom (x_g = -0.01): outside
+                   [0.07, 0.05, 0.0],     # beyond the finger gap: outside
+                   [0.07, 0.0, 0.02]], dtype=np.float32)   # above the hand height: outside
+    ind, pts = do.collect_pc_(grasp, pc, np.eye(4), 0.06, hp, min_point_limit=1)
+    np.testing.assert_array_equal(ind, [0])
+    np.testing.assert_allclose(pts[0], [0.03, 0.0, 0.0], atol=1e-9)
+
+
+def test_frames_match_the_restatement_bit_for_bit():
+    grasps, T, pc = synth.dataset_view(3, 2000, 12)
+    hp = _hand_points()
+    frames = dc.frames_from_configs(grasps, T, 0.06)
+    for g in range(len(grasps)):
+        ind, pts = do.collect_pc_(grasps[g], pc, T, 0.06, hp, min_point_limit=0)
+        m = frames[g, 3:].reshape(3, 3)
+        want = (np.dot(m, (pc - frames[g, :3]).T)).T[ind]
+        np.testing.assert_array_equal(pts, want)
+
+
+def test_labels():
+    g = np.zeros((4, 10))
+    g[:, -2] = [0.2, 0.6, 0.4, 1.0]
+    g[:, -1] = [0.0, 0.0, 50.0, 0.0]      # 0.4 + 0.5 = 0.9
+    lab = dc.labels_from_scores(g, thresh_good=0.3, thresh_bad=0.6)
+    np.testing.assert_array_equal(lab, [1, 0, 0, 0])
+    lab = dc.labels_from_scores(g, thresh_good=0.3, thresh_bad=0.95)
+    np.testing.assert_array_equal(lab, [1, -1, -1, 0])
+
+
+def test_getitem_tail_resample_rule():
+    pts = np.arange(30, dtype=np.float64).reshape(10, 3)
+    calls = []
+
+    def choice(n, size, replace):
+        calls.append((n, size, replace))
+        return np.arange(size) % n
+
+    g = np.zeros(10)
+    out = do.getitem_tail(g, pts, 10, 0.3, 0.6, choice)       # len == N: WITH replacement (:1104 uses >)
+    assert calls[-1] == (10, 10, True) and out[0].shape == (3, 10) and out[1] == 1
+    do.getitem_tail(g, pts, 9, 0.3, 0.6, choice)
+    assert calls[-1] == (10, 9, False)
+    g[-2] = 0.45
+    assert do.getitem_tail(g, pts, 9, 0.3, 0.6, choice) is None
+    assert do.getitem_tail(g, None, 9, 0.3, 0.6, choice) is None
