@@ -108,10 +108,7 @@ def online_workload(args, dev, rank, n_gpus, dist):
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(dist, elapsed, dev)
     # stage split with events on the launch stream
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     e[0].record()
@@ -166,10 +163,7 @@ def train_workload(args, dev, rank, n_gpus, dist):
         loss, _ = trainer.step(x, target)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(dist, elapsed, dev)
     if rank == 0:
         flop = 3.0 * B * flop_per_candidate(P, k)
         print(json.dumps({
@@ -197,10 +191,7 @@ def voxel_workload(args, dev, rank, n_gpus, dist):
         out = hv.get_voxel_fun(scene, n)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(dist, elapsed, dev)
     M = out.shape[0]
     bitmap = n ** 3 // 8
     if rank == 0:
@@ -217,6 +208,16 @@ def voxel_workload(args, dev, rank, n_gpus, dist):
 
 
 SETTLE_STEPS = 50
+
+
+def max_over_ranks(dist, elapsed, dev):
+    """MAX of the per-rank wall time of the timed region (device tensor under RCCL, host tensor under gloo)."""
+    if dist is None:
+        return elapsed
+    on_dev = dist.get_backend() == "nccl"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if on_dev else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def main():
@@ -244,12 +245,23 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # PNGPD_BENCH_BACKEND=gloo rehearses the multi-process flow on a box with fewer GPUs than
+        # ranks (ranks then share devices); the driver's runs use RCCL, one rank per GPU.
+        backend = os.environ.get("PNGPD_BENCH_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" and local_rank >= ndev:
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+        dev_index = local_rank % max(ndev, 1)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
     n_gpus = world
     if n_gpus != args.gpus and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -285,10 +297,7 @@ def main():
         logp, trans = model(x)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(dist, elapsed, dev)
     assert torch.isfinite(logp).all()
 
     # dominant kernel: fused conv stack, timed alone with HIP events on the launch stream
