@@ -106,17 +106,42 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ A, 
     }
 }
 
+// The finalize kernels sum nblk partials per column.  Block = 16 columns x 16 row lanes: every row
+// lane sums every 16th partial, the 16 lane sums are then added in a fixed order (reproducible).
+constexpr int FIN_COLS = 16, FIN_LANES = 16;
+
+__device__ __forceinline__ void sum_partials2(const double* __restrict__ part, int nblk, int C, int c, int rl,
+                                              double& s1, double& s2) {
+    __shared__ double sh[2][FIN_LANES][FIN_COLS];
+    const int cl = threadIdx.x & (FIN_COLS - 1);
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int i = rl; i < nblk; i += FIN_LANES) {
+            a += part[((size_t)i * 2 + 0) * C + c];
+            b += part[((size_t)i * 2 + 1) * C + c];
+        }
+    sh[0][rl][cl] = a;
+    sh[1][rl][cl] = b;
+    __syncthreads();
+    s1 = 0.0;
+    s2 = 0.0;
+    if (rl == 0)
+        for (int k = 0; k < FIN_LANES; ++k) {
+            s1 += sh[0][k][cl];
+            s2 += sh[1][k][cl];
+        }
+}
+
 // Finalise batch statistics: mean, rstd; update running stats (momentum, unbiased variance).
-__global__ void k_stats_finalize(const double* __restrict__ part, int nblk, const float* __restrict__ A, int M,
-                                 int C, float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                 float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < nblk; ++i) {
-        s1 += part[((size_t)i * 2 + 0) * C + c];
-        s2 += part[((size_t)i * 2 + 1) * C + c];
-    }
+__global__ __launch_bounds__(256) void k_stats_finalize(const double* __restrict__ part, int nblk,
+                                                        const float* __restrict__ A, int M, int C, float momentum,
+                                                        float* __restrict__ mean, float* __restrict__ rstd,
+                                                        float* __restrict__ running_mean,
+                                                        float* __restrict__ running_var) {
+    const int c = blockIdx.x * FIN_COLS + (threadIdx.x & (FIN_COLS - 1)), rl = threadIdx.x / FIN_COLS;
+    double s1, s2;
+    sum_partials2(part, nblk, C, c, rl, s1, s2);
+    if (rl != 0 || c >= C) return;
     const double dm = s1 / M;                      // mean of the shifted data
     const double mu = (double)A[c] + dm;
     double var = s2 / M - dm * dm;
@@ -131,15 +156,13 @@ __global__ void k_stats_finalize(const double* __restrict__ part, int nblk, cons
 }
 
 // m1 = s1/M, m2 = s2/M; dgamma = s2, dbeta = s1
-__global__ void k_bnbwd_finalize(const double* __restrict__ part, int nblk, int M, int C, float* __restrict__ m1,
-                                 float* __restrict__ m2, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < nblk; ++i) {
-        s1 += part[((size_t)i * 2 + 0) * C + c];
-        s2 += part[((size_t)i * 2 + 1) * C + c];
-    }
+__global__ __launch_bounds__(256) void k_bnbwd_finalize(const double* __restrict__ part, int nblk, int M, int C,
+                                                        float* __restrict__ m1, float* __restrict__ m2,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * FIN_COLS + (threadIdx.x & (FIN_COLS - 1)), rl = threadIdx.x / FIN_COLS;
+    double s1, s2;
+    sum_partials2(part, nblk, C, c, rl, s1, s2);
+    if (rl != 0 || c >= C) return;
     m1[c] = (float)(s1 / M);
     m2[c] = (float)(s2 / M);
     dgamma[c] = (float)s2;
@@ -206,23 +229,38 @@ __global__ __launch_bounds__(256) void k_maxpool_bn(const float* __restrict__ y3
     }
 }
 
-// sparse BN-backward reductions for the pooled layer: one thread per channel, loop over candidates
+// sparse BN-backward reductions for the pooled layer: 16 channels x 16 candidate lanes per block
 //   g = dpooled[b,c] * (relu ? pooled[b,c] > 0 : 1); yhat at the arg row
-__global__ void k_pool_bwd_reduce(const float* __restrict__ dpooled, const float* __restrict__ pooled,
-                                  const int* __restrict__ arg, const float* __restrict__ y3,
-                                  const float* __restrict__ mean, const float* __restrict__ rstd, int B, int P, int C,
-                                  int relu, float* __restrict__ m1, float* __restrict__ m2,
-                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void k_pool_bwd_reduce(const float* __restrict__ dpooled,
+                                                         const float* __restrict__ pooled,
+                                                         const int* __restrict__ arg, const float* __restrict__ y3,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, int B, int P, int C,
+                                                         int relu, float* __restrict__ m1, float* __restrict__ m2,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double sh[2][FIN_LANES][FIN_COLS];
+    const int cl = threadIdx.x & (FIN_COLS - 1), rl = threadIdx.x / FIN_COLS;
+    const int c = blockIdx.x * FIN_COLS + cl;
     double s1 = 0.0, s2 = 0.0;
-    const float mu = mean[c], rs = rstd[c];
-    for (int b = 0; b < B; ++b) {
-        float g = dpooled[(size_t)b * C + c];
-        if (relu && !(pooled[(size_t)b * C + c] > 0.f)) g = 0.f;
-        const float yh = (y3[((size_t)b * P + arg[(size_t)b * C + c]) * C + c] - mu) * rs;
-        s1 += (double)g;
-        s2 += (double)(g * yh);
+    if (c < C) {
+        const float mu = mean[c], rs = rstd[c];
+        for (int b = rl; b < B; b += FIN_LANES) {
+            float g = dpooled[(size_t)b * C + c];
+            if (relu && !(pooled[(size_t)b * C + c] > 0.f)) g = 0.f;
+            const float yh = (y3[((size_t)b * P + arg[(size_t)b * C + c]) * C + c] - mu) * rs;
+            s1 += (double)g;
+            s2 += (double)(g * yh);
+        }
+    }
+    sh[0][rl][cl] = s1;
+    sh[1][rl][cl] = s2;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    s1 = 0.0;
+    s2 = 0.0;
+    for (int k = 0; k < FIN_LANES; ++k) {
+        s1 += sh[0][k][cl];
+        s2 += sh[1][k][cl];
     }
     const double M = (double)B * P;
     m1[c] = (float)(s1 / M);
@@ -380,11 +418,19 @@ __global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ d
             part[(size_t)blockIdx.x * 192 + cl * 3 + j] = sp[0][cl][j] + sp[1][cl][j] + sp[2][cl][j] + sp[3][cl][j];
 }
 
-__global__ void k_reduce_double(const double* __restrict__ part, int nblk, int n, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(256) void k_reduce_double(const double* __restrict__ part, int nblk, int n,
+                                                       float* __restrict__ out) {
+    __shared__ double sh[FIN_LANES][FIN_COLS];
+    const int cl = threadIdx.x & (FIN_COLS - 1), rl = threadIdx.x / FIN_COLS;
+    const int i = blockIdx.x * FIN_COLS + cl;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + i];
+    if (i < n)
+        for (int b = rl; b < nblk; b += FIN_LANES) s += part[(size_t)b * n + i];
+    sh[rl][cl] = s;
+    __syncthreads();
+    if (rl != 0 || i >= n) return;
+    s = 0.0;
+    for (int k = 0; k < FIN_LANES; ++k) s += sh[k][cl];
     out[i] = (float)s;
 }
 
@@ -542,7 +588,7 @@ hipError_t t_bn_stats(const float* A, int M, int C, float momentum, double* part
     const int nblk = t_red_blocks(M);
     hipLaunchKernelGGL(k_colreduce, dim3((C + 63) / 64, nblk), dim3(256), 0, s, A, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, 0, part);
-    hipLaunchKernelGGL(k_stats_finalize, grid1(C), dim3(256), 0, s, part, nblk, A, M, C, momentum, mean, rstd,
+    hipLaunchKernelGGL(k_stats_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, A, M, C, momentum, mean, rstd,
                        running_mean, running_var);
     return hipGetLastError();
 }
@@ -559,7 +605,7 @@ hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean
     const int nblk = t_red_blocks(M);
     hipLaunchKernelGGL(k_colreduce, dim3((C + 63) / 64, nblk), dim3(256), 0, s, (const float*)dh, h, y, mean, rstd, M,
                        C, 1, part);
-    hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta);
+    hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta);
     hipLaunchKernelGGL(k_bn_bwd_dense, grid1((size_t)M * C), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, m1, m2,
                        (size_t)M * C, C);
     return hipGetLastError();
@@ -574,7 +620,7 @@ hipError_t t_maxpool_bn(const float* y3, const float* mean, const float* rstd, c
 hipError_t t_pool_bwd(float* y3, const float* dpooled, const float* pooled, const int* arg, const float* mean,
                       const float* rstd, const float* gamma, int B, int P, int C, int relu, float* m1, float* m2,
                       float* dgamma, float* dbeta, hipStream_t s) {
-    hipLaunchKernelGGL(k_pool_bwd_reduce, grid1(C), dim3(256), 0, s, dpooled, pooled, arg, (const float*)y3, mean, rstd,
+    hipLaunchKernelGGL(k_pool_bwd_reduce, grid1(C, FIN_COLS), dim3(256), 0, s, dpooled, pooled, arg, (const float*)y3, mean, rstd,
                        B, P, C, relu, m1, m2, dgamma, dbeta);
     hipLaunchKernelGGL(k_pool_bwd_dense, grid1((size_t)B * P * C), dim3(256), 0, s, y3, mean, rstd, gamma,
                        (const float*)m1, (const float*)m2, (size_t)B * P * C, C);
@@ -602,7 +648,7 @@ hipError_t t_conv1_bwd(const float* dy1, const float* X3, const float* W1, int M
                        float* dX3, hipStream_t s) {
     const int nblk = t_red_blocks(M);
     hipLaunchKernelGGL(k_conv1_wgrad, dim3(nblk), dim3(256), 0, s, dy1, X3, M, part);
-    hipLaunchKernelGGL(k_reduce_double, grid1(192), dim3(256), 0, s, (const double*)part, nblk, 192, dW1);
+    hipLaunchKernelGGL(k_reduce_double, grid1(192, FIN_COLS), dim3(256), 0, s, (const double*)part, nblk, 192, dW1);
     if (dX3 != nullptr) hipLaunchKernelGGL(k_conv1_dgrad, dim3((M + 3) / 4), dim3(256), 0, s, dy1, W1, dX3, M);
     return hipGetLastError();
 }
