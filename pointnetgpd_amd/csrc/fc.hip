@@ -168,40 +168,48 @@ hipError_t launch_score(const float* logp, int B, int k, float* probs, int64_t* 
 // The dropped xl*wl term is 2^-16 relative, so the result is f32-grade (measured 1e-5 on the
 // log-probabilities) at 3 bf16 MFMAs per 16x-slower f32 MFMA.  Weights are split and laid out in
 // fragment order on the host (pack.cpp: pack_fc_split); activations are split while they are
-// staged into LDS.  Tile 64 x 128 x 32, 4 waves as 2 x 2, double-buffered, one barrier per k-block.
+// staged into LDS.  Tile {64,32} x 128 x 32, double-buffered, one barrier per k-block.
 // ------------------------------------------------------------------------------------------
 namespace pngpd {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-constexpr int X3_BM = 64, X3_BN = 128, X3_BK = 32;
-constexpr int X3_A_BYTES = 2 * 2 * 2 * 1024;     // [mt2][ks2][plane2] fragments of 1 KiB
-constexpr int X3_B_BYTES = 4 * 2 * 2 * 1024;     // [nt4][ks2][plane2]
-constexpr int X3_STAGE = X3_A_BYTES + X3_B_BYTES;
+constexpr int X3_BN = 128, X3_BK = 32;
+constexpr int X3_B_BYTES = 4 * 2 * 2 * 1024;     // [nt4][ks2][plane2] fragments of 1 KiB
 
+// BM = 64: 4 waves as 2 x 2, each 32 rows x 64 columns.  BM = 32: 4 waves as 1 x 4, each 32 x 32;
+// twice as many workgroups, used when the 64-row grid would leave CUs with a single workgroup
+// (the layer is latency-bound then: 12 MFMAs per k-block cannot cover a global load).
+template <int BM>
 __global__ __launch_bounds__(256) void fc_bf16x3_kernel(const float* __restrict__ X, const char* __restrict__ Wp,
                                                         const float* __restrict__ bias, float* __restrict__ Y,
                                                         int M, int N, int K, int relu) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];
+    constexpr int MT = BM / 32;                       // row tiles per workgroup
+    constexpr int T = MT == 2 ? 2 : 1;                // column tiles per wave
+    constexpr int A_BYTES = MT * 2 * 2 * 1024;        // [mt][ks2][plane2]
+    constexpr int STAGE = A_BYTES + X3_B_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * X3_BM, n0 = blockIdx.x * X3_BN;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = MT == 2 ? wave >> 1 : 0, wn = MT == 2 ? wave & 1 : wave;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * X3_BN;
     const int nkb = K / X3_BK, ksteps = K / 16;
 
-    // A staging: thread -> (row 0..63, k-group g 0..3 of 8 floats)
+    // A staging: thread -> (row 0..BM-1, k-group g 0..3 of 8 floats)
     const int arow = tid >> 2, ag = tid & 3;
+    const bool a_thread = arow < BM;
     const int a_mt = arow >> 5, a_r = arow & 31, a_ks = ag >> 1, a_h = ag & 1;
     // fragment slot inside its 1 KiB piece, XOR-swizzled so that the four k-groups of a row fall in
     // four different 16-byte slots (writes) while a reading wave still touches each slot once
     const int a_slot = 32 * a_h + (a_r ^ ag);
     const int a_off = ((a_mt * 2 + a_ks) * 2) * 1024 + a_slot * 16;          // hi plane; lo plane + 1024
-    const bool a_ok = (m0 + arow) < M;
+    const bool a_ok = a_thread && (m0 + arow) < M;
     const float* a_src = X + (size_t)(a_ok ? m0 + arow : 0) * K + ag * 8;
 
     auto stage_b = [&](int kb, char* stage) {
         // 16 pieces of 1 KiB: (nt 0..3, ks 0..1, plane 0..1); wave w takes nt = w
-        char* dst = stage + X3_A_BYTES + wave * 4 * 1024;
+        char* dst = stage + A_BYTES + wave * 4 * 1024;
         const char* src = Wp + ((size_t)((n0 / 32 + wave) * ksteps + kb * 2) * 2) * 1024;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -217,6 +225,7 @@ __global__ __launch_bounds__(256) void fc_bf16x3_kernel(const float* __restrict_
         }
     };
     auto store_a = [&](const float4& v0, const float4& v1, char* stage) {
+        if (!a_thread) return;
         const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         bf16x8_t hi, lo;
 #pragma unroll
@@ -228,15 +237,17 @@ __global__ __launch_bounds__(256) void fc_bf16x3_kernel(const float* __restrict_
         *(bf16x8_t*)(stage + a_off + 1024) = lo;
     };
 
-    f32x16 acc[2] = {f32x16{0}, f32x16{0}};
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x16{0};
     float4 v0, v1;
     stage_b(0, smem);
     load_a(0, v0, v1);
     store_a(v0, v1, smem);
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
-        char* cur = smem + (kb & 1) * X3_STAGE;
-        char* nxt = smem + ((kb + 1) & 1) * X3_STAGE;
+        char* cur = smem + (kb & 1) * STAGE;
+        char* nxt = smem + ((kb + 1) & 1) * STAGE;
         const bool more = kb + 1 < nkb;
         if (more) {
             stage_b(kb + 1, nxt);
@@ -249,8 +260,8 @@ __global__ __launch_bounds__(256) void fc_bf16x3_kernel(const float* __restrict_
             const bf16x8_t ah = *(const bf16x8_t*)pa;
             const bf16x8_t al = *(const bf16x8_t*)(pa + 1024);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const char* pb = cur + X3_A_BYTES + (((wn * 2 + t) * 2 + ks) * 2) * 1024 + lane * 16;
+            for (int t = 0; t < T; ++t) {
+                const char* pb = cur + A_BYTES + (((wn * T + t) * 2 + ks) * 2) * 1024 + lane * 16;
                 const bf16x8_t bh = *(const bf16x8_t*)pb;
                 const bf16x8_t bl = *(const bf16x8_t*)(pb + 1024);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
@@ -262,8 +273,8 @@ __global__ __launch_bounds__(256) void fc_bf16x3_kernel(const float* __restrict_
         __syncthreads();
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int col = n0 + (wn * 2 + t) * 32 + r;
+    for (int t = 0; t < T; ++t) {
+        const int col = n0 + (wn * T + t) * 32 + r;
         const float bv = bias[col];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -280,8 +291,14 @@ __global__ __launch_bounds__(256) void fc_bf16x3_kernel(const float* __restrict_
 hipError_t launch_fc_bf16x3(const float* X, const void* Wp, const float* b, float* Y, int M, int N, int K, int relu,
                             hipStream_t s) {
     if (!X || !Wp || !b || !Y || M < 1 || N % X3_BN != 0 || K % X3_BK != 0) return hipErrorInvalidValue;
-    dim3 grid(N / X3_BN, (M + X3_BM - 1) / X3_BM);
-    hipLaunchKernelGGL(fc_bf16x3_kernel, grid, dim3(256), 0, s, X, (const char*)Wp, b, Y, M, N, K, relu);
+    const long long wg64 = (long long)(N / X3_BN) * ((M + 63) / 64);
+    if (wg64 >= 1024) {      // at least ~4 workgroups per CU with 64-row tiles
+        dim3 grid(N / X3_BN, (M + 63) / 64);
+        hipLaunchKernelGGL(fc_bf16x3_kernel<64>, grid, dim3(256), 0, s, X, (const char*)Wp, b, Y, M, N, K, relu);
+    } else {
+        dim3 grid(N / X3_BN, (M + 31) / 32);
+        hipLaunchKernelGGL(fc_bf16x3_kernel<32>, grid, dim3(256), 0, s, X, (const char*)Wp, b, Y, M, N, K, relu);
+    }
     return hipGetLastError();
 }
 
