@@ -196,7 +196,13 @@ class Trainer:
         train_backward(model, x, logp, dlogp, None, self._ws, lambda p: self._gview[id(p)])
         ws = self.world_size()
         if ws > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)   # the one collective
+            # the one collective of the path: the flat gradient bucket, summed (Adam divides by ws)
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+            else:   # a host-memory backend (gloo): stage through the host
+                host = self.flat_g.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat_g.copy_(host)
         self.step_count += 1
         lib = _lib.load()
         dev = self.flat_p.device
