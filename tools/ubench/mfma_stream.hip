@@ -150,6 +150,113 @@ __global__ __launch_bounds__(512) void k_stream(const bf16x8* wsrc, const bf16x8
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// The consume loop of the conv-stack kernel, lone wave: per tile 4 ds_read_b128 (next tile's A fragments,
+// alternating register sets), 8 in-place chains of 4 MFMAs, 2 v_max3 per chain after the following chain.
+//   V = 0: as in the kernel   1: without the LDS reads   2: without the max3   3: neither
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+__device__ __forceinline__ f32x4 chain4(const bf16x8 (&af)[4], const bf16x8 (&b)[4]) {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], b[k], z, 0, 0, 0);
+    return z;
+}
+
+template <int V>
+__device__ __forceinline__ void consume(const bf16x8 (&af)[4], const bf16x8 (&bw)[8][4], f32x4& carry, float (&rm)[8],
+                                        bf16x8 (&afn)[4], const bf16x8* next = nullptr) {
+    f32x4 accA = carry, accB;
+#pragma unroll
+    for (int n = 0; n < 8; n += 2) {
+        if (V == 4) {            // one fragment of the next tile per chain pair, placed inside the first chain
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bw[n][0], z, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            afn[n >> 1] = next[(n >> 1) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k], bw[n][k], z, 0, 0, 0);
+            accB = z;
+        } else {
+            accB = chain4(af, bw[n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int pn = (n + 7) & 7;
+        if (!(V & 2)) rm[pn] = max3f(rm[pn], max3f(accA[0], accA[1], accA[2]), accA[3]);
+        else rm[pn] += accA[0];
+        __builtin_amdgcn_sched_barrier(0);
+        accA = chain4(af, bw[n + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(V & 2)) rm[n] = max3f(rm[n], max3f(accB[0], accB[1], accB[2]), accB[3]);
+        else rm[n] += accB[0];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    carry = accA;
+}
+
+template <int V>
+__global__ __launch_bounds__(512) void k_loop(const bf16x8* wsrc, const bf16x8* asrc, float* out,
+                                              unsigned long long* cyc, int iters) {
+    __shared__ bf16x8 s_a[16 * 4 * 64];        // 16 tiles of A fragments
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 16 * 4 * 64; i += blockDim.x) s_a[i] = asrc[i & 255];
+    __syncthreads();
+    bf16x8 bw[8][4];
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bw[n][k] = wsrc[(n * 4 + k) * 64 + lane];
+    float rm[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) rm[n] = -1e30f;
+    f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 afA[4], afB[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) afA[k] = s_a[k * 64 + lane], afB[k] = s_a[(4 + k) * 64 + lane];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        for (int i = 0; i < 8; ++i) {
+            if (!(V & 1) && V != 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) afB[k] = s_a[((2 * i + 1) * 4 + k) * 64 + lane];
+            }
+            if (V == 4) {
+                consume<V>(afA, bw, carry, rm, afB, s_a + ((2 * i + 1) * 4) * 64 + lane);
+                consume<V>(afB, bw, carry, rm, afA, s_a + ((2 * i + 2 > 15 ? 15 : 2 * i + 2) * 4) * 64 + lane);
+                continue;
+            }
+            consume<V>(afA, bw, carry, rm, afB);
+            if (!(V & 1)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) afA[k] = s_a[((2 * i + 2 > 15 ? 15 : 2 * i + 2) * 4 + k) * 64 + lane];
+            }
+            consume<V>(afB, bw, carry, rm, afA);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = carry[0];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) r += rm[n];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    (void)wave;
+}
+
+template <int V>
+static void run_loop(const char* name, const bf16x8* w, const bf16x8* a, float* out, unsigned long long* cyc, int blocks) {
+    const int iters = 250;                    // x 16 tiles x 32 MFMAs
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL(k_loop<V>, dim3(blocks), dim3(256), 0, 0, w, a, out, cyc, iters);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h(blocks);
+        hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost);
+        double mean = 0;
+        for (auto v : h) mean += (double)v;
+        mean /= blocks;
+        printf("%-36s rep %d: %.2f ticks/MFMA (%.0f per tile)\n", name, rep, mean / (iters * 16 * 32.0), mean / (iters * 16.0));
+    }
+}
+
 template <int V>
 static void run(const char* name, const bf16x8* w, const bf16x8* a, float* out, unsigned long long* cyc, int blocks) {
     const int iters = 4000;
@@ -203,5 +310,8 @@ int main() {
     run<7>("four chains alternating", w, a, out, cyc, blocks);
     run<8>("chain-major, C = 0 starts", w, a, out, cyc, blocks);
     run<9>("chain-major, pairs", w, a, out, cyc, blocks);
+    run_loop<0>("consume loop as in the kernel", w, a, out, cyc, blocks);
+    run_loop<1>("consume loop, no LDS reads", w, a, out, cyc, blocks);
+    run_loop<4>("consume loop, LDS read inside chain", w, a, out, cyc, blocks);
     return 0;
 }
