@@ -63,3 +63,15 @@ def test_getitem_tail_resample_rule():
     g[-2] = 0.45
     assert do.getitem_tail(g, pts, 9, 0.3, 0.6, choice) is None
     assert do.getitem_tail(g, None, 9, 0.3, 0.6, choice) is None
+
+
+def test_restatement_regression_vectors():
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_crop_small.npz"))
+    grasps, T, pc = synth.dataset_view(int(d["seed"]), int(d["S"]), int(d["G"]))
+    hp = _hand_points()
+    for g in range(len(grasps)):
+        ind, gpc = do.collect_pc_(grasps[g], pc, T, 0.06, hp, min_point_limit=0)
+        assert len(ind) == int(d["counts"][g])
+        if len(ind) >= 4:
+            np.testing.assert_array_equal(gpc[:4], d["first_points"][g])

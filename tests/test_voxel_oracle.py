@@ -51,3 +51,12 @@ def test_output_is_sorted_unique_float32():
     order = np.lexsort((got[:, 2], got[:, 1], got[:, 0]))
     np.testing.assert_array_equal(order, np.arange(len(got)))
     assert len(np.unique(got, axis=0)) == len(got)
+
+
+def test_restatement_regression_vectors():
+    import os
+    from pointnetgpd_amd import synth
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voxel_small.npz"))
+    pts = synth.scene_points(int(d["seed"]), int(d["S"]), float(d["cube"]))
+    for n in d["n"]:
+        np.testing.assert_array_equal(vo.get_voxel_fun(pts, int(n)), d[f"out_n{int(n)}"])
