@@ -88,8 +88,26 @@ def build_oracle_c(force: bool = False) -> str:
     return ORACLE_C_PATH
 
 
+EXAMPLE_PATH = os.path.join(ROOT, "examples", "score_candidates")
+
+
+def build_example(force: bool = False) -> str:
+    """The plain-C host of examples/score_candidates.c (gcc, linked against libpngpd.so and the HIP runtime)."""
+    src = os.path.join(ROOT, "examples", "score_candidates.c")
+    if not os.path.exists(src):
+        return ""
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if force or _newer(EXAMPLE_PATH, [src, LIB_PATH, os.path.join(ROOT, "include", "pngpd.h")]):
+        _run(["gcc", "-O2", "-std=c11", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"),
+              "-I", os.path.join(ROOT, "include"), src, "-o", EXAMPLE_PATH,
+              "-L", os.path.dirname(LIB_PATH), "-lpngpd", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+              "-Wl,-rpath," + os.path.dirname(LIB_PATH), "-Wl,-rpath," + os.path.join(rocm, "lib")])
+    return EXAMPLE_PATH
+
+
 def build_all(force: bool = False) -> None:
     build_library(force)
+    build_example(force)
     build_probe(force)
     build_oracle_c(force)
 
