@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void fc_f32_kernel(const float* __restrict__ X
     const int lcol = (tid & 7) * 4;   // 0..28
 
     f32x16 acc = {0};
-    for (int k0 = 0; k0 < K; k0 += FC_BK) {
-        float4 va[2], vb[2];
+    float4 va[2], vb[2];
+    auto load_tile = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = lrow + 32 * i;
@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256) void fc_f32_kernel(const float* __restrict__ X
             va[i] = gm < M ? *(const float4*)(X + (size_t)gm * K + k0 + lcol) : make_float4(0, 0, 0, 0);
             vb[i] = *(const float4*)(W + (size_t)(n0 + row) * K + k0 + lcol);
         }
+    };
+    load_tile(0);
+    for (int k0 = 0; k0 < K; k0 += FC_BK) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -52,6 +55,7 @@ __global__ __launch_bounds__(256) void fc_f32_kernel(const float* __restrict__ X
             pb[0] = vb[i].x; pb[1] = vb[i].y; pb[2] = vb[i].z; pb[3] = vb[i].w;
         }
         __syncthreads();
+        if (k0 + FC_BK < K) load_tile(k0 + FC_BK);     // in flight during this tile's MFMAs
         const float* ra = sA + (wm * 32 + r) * FC_LD + h;
         const float* rb = sB + (wn * 32 + r) * FC_LD + h;
 #pragma unroll

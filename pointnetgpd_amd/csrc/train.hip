@@ -311,14 +311,17 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
     const int arow = tid >> 3, acol = (tid & 7) * 4;        // A tile 64x32: 2 float4 per thread
     const int brow = tid >> 4, bcol = (tid & 15) * 4;       // B tile 32x64: 2 float4 per thread
     f32x16 acc = {0};
-    for (int n0 = 0; n0 < N; n0 += GB_K) {
-        float4 va[2], vb[2];
+    float4 va[2], vb[2];
+    auto load_tile = [&](int n0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int gm = m0 + arow + 32 * i;
             va[i] = gm < M ? *(const float4*)(dY + (size_t)gm * N + n0 + acol) : make_float4(0, 0, 0, 0);
             vb[i] = *(const float4*)(W + (size_t)(n0 + brow + 16 * i) * Kout + k0 + bcol);
         }
+    };
+    load_tile(0);
+    for (int n0 = 0; n0 < N; n0 += GB_K) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
             *(float4*)(sB + (brow + 16 * i) * GB_N + bcol) = vb[i];
         }
         __syncthreads();
+        if (n0 + GB_K < N) load_tile(n0 + GB_K);       // in flight during this tile's MFMAs
         const float* ra = sA + (wm * 32 + r) * (GB_K + 1) + h;
         const float* rb = sB + h * GB_N + wn * 32 + r;
 #pragma unroll
@@ -355,8 +359,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     const int row_end = min(M, row_begin + rows_per_chunk);
     const int lrow = tid >> 4, lcol = (tid & 15) * 4;        // 32x64 tile: 2 float4 per thread
     f32x16 acc = {0};
-    for (int mb = row_begin; mb < row_end; mb += GB_K) {
-        float4 va[2], vb[2];
+    float4 va[2], vb[2];
+    auto load_tile = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int gm = mb + lrow + 16 * i;
@@ -364,6 +368,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             va[i] = ok ? *(const float4*)(dY + (size_t)gm * N + n0 + lcol) : make_float4(0, 0, 0, 0);
             vb[i] = ok ? *(const float4*)(Hm + (size_t)gm * K + k0 + lcol) : make_float4(0, 0, 0, 0);
         }
+    };
+    if (row_begin < row_end) load_tile(row_begin);
+    for (int mb = row_begin; mb < row_end; mb += GB_K) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -371,6 +378,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             *(float4*)(sB + (lrow + 16 * i) * GB_N + lcol) = vb[i];
         }
         __syncthreads();
+        if (mb + GB_K < row_end) load_tile(mb + GB_K);  // in flight during this tile's MFMAs
         const float* ra = sA + h * GB_M + wm * 32 + r;      // A[i = n][kk = m]
         const float* rb = sB + h * GB_N + wn * 32 + r;      // B[kk = m][j = k]
 #pragma unroll
