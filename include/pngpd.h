@@ -258,14 +258,15 @@ int pngpd_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_de
                     int step, float grad_scale, void* stream);
 
 /*
- * Diagnostic: time the fused conv-stack kernel alone.  Launches the STN stack (which = 0) or the
- * trunk stack (which = 1; uses an identity transform) `iters` times on `stream` between two HIP
- * events recorded on that stream, waits for the second event and returns the mean kernel time in
- * milliseconds.  Used by bench.py for the roofline figure; no counterpart in the reference.
+ * Diagnostic: pngpd_forward_infer with the two conv-stack launches of the step bracketed by HIP
+ * events recorded on `stream`; waits for the trunk launch to finish and returns the two kernel
+ * durations in milliseconds (conv_ms_out[0] = STN stack, [1] = trunk stack).  The model needs a
+ * trunk.  Used by bench.py for the roofline figure; no counterpart in the reference.
  */
-int pngpd_profile_conv_stack(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
-                             int precision, int which, int iters, void* workspace_dev,
-                             size_t workspace_bytes, float* mean_ms_out, void* stream);
+int pngpd_forward_infer_timed(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
+                              int precision, float* logp_dev, float* trans_dev, float* feat_dev,
+                              void* workspace_dev, size_t workspace_bytes, float* conv_ms_out,
+                              void* stream);
 
 #ifdef __cplusplus
 }

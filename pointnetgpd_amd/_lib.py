@@ -38,8 +38,8 @@ SIGNATURES = {
     "pngpd_forward_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "pngpd_forward_infer": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
-    "pngpd_profile_conv_stack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                                         c_size_t, POINTER(c_float), c_void_p]),
+    "pngpd_forward_infer_timed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_size_t, c_void_p, c_void_p]),
     "pngpd_crop_workspace_bytes": (c_size_t, [c_int, c_int]),
     "pngpd_crop_count": (c_int, [c_void_p, c_int, c_void_p, c_int, POINTER(c_double), c_void_p, c_size_t, c_void_p,
                                  c_void_p, c_void_p]),

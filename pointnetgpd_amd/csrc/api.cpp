@@ -246,9 +246,10 @@ size_t pngpd_forward_workspace_bytes(const pngpd_model* m, int B) {
     return Workspace::floats(B) * sizeof(float);
 }
 
-int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
-                        int precision, float* logp_dev, float* trans_dev, float* feat_dev,
-                        void* workspace_dev, size_t workspace_bytes, void* stream) {
+// ev: nullptr, or 4 events recorded on the stream around the STN (0,1) and trunk (2,3) conv-stack launches
+static int forward_impl(const pngpd_model* m, const float* x_dev, int layout, int B, int P, int precision,
+                        float* logp_dev, float* trans_dev, float* feat_dev, void* workspace_dev,
+                        size_t workspace_bytes, void* stream, hipEvent_t* ev) {
     if (!m || !x_dev) return fail(PNGPD_ERR_INVALID, "pngpd_forward_infer: NULL model or input");
     if (!m->loaded) return fail(PNGPD_ERR_STATE, "pngpd_forward_infer: weights not loaded");
     if (B < 1) return fail(PNGPD_ERR_SHAPE, "batch must be >= 1, got %d", B);
@@ -272,48 +273,48 @@ int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, in
 
     // STN3d: conv stack (ReLU after the max), then the 1024-512-256-9 regressor + identity
     float* trans = trans_dev ? trans_dev : ws.trans;
+    if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     HIP_TRY(launch_stack(stack_args(m->stn, precision, x_dev, layout, B, P, nullptr, ws.pooled, 1), s));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], s));
     int rc = run_fc_chain(m->stn_fc, ws.pooled, ws, trans, B, pngpd::FC_TAIL_ADD_IDENTITY, precision, s);
     if (rc) return rc;
     if (!(m->parts & PNGPD_PART_TRUNK)) return PNGPD_OK;
 
     // PointNetfeat: points times trans, conv stack without the last ReLU
     float* feat = feat_dev ? feat_dev : ws.feat;
+    if (ev) HIP_TRY(hipEventRecord(ev[2], s));
     HIP_TRY(launch_stack(stack_args(m->trunk, precision, x_dev, layout, B, P, trans, feat, 0), s));
+    if (ev) HIP_TRY(hipEventRecord(ev[3], s));
     if (!(m->parts & PNGPD_PART_HEAD) || !logp_dev) return PNGPD_OK;
 
     // PointNetCls head + log_softmax
     return run_fc_chain(m->head_fc, feat, ws, logp_dev, B, pngpd::FC_TAIL_LOG_SOFTMAX, precision, s);
 }
 
-int pngpd_profile_conv_stack(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
-                             int precision, int which, int iters, void* workspace_dev,
-                             size_t workspace_bytes, float* mean_ms_out, void* stream) {
-    if (!m || !x_dev || !mean_ms_out) return fail(PNGPD_ERR_INVALID, "pngpd_profile_conv_stack: NULL argument");
-    if (!m->loaded) return fail(PNGPD_ERR_STATE, "pngpd_profile_conv_stack: weights not loaded");
-    if (B < 1 || P != m->num_points || iters < 1) return fail(PNGPD_ERR_SHAPE, "pngpd_profile_conv_stack: bad B/P/iters");
-    if (which != 0 && !(m->parts & PNGPD_PART_TRUNK)) return fail(PNGPD_ERR_STATE, "model has no trunk");
-    if (!workspace_dev || workspace_bytes < pngpd_forward_workspace_bytes(m, B))
-        return fail(PNGPD_ERR_WORKSPACE, "workspace too small");
-    hipStream_t s = (hipStream_t)stream;
-    Workspace ws(workspace_dev, B);
-    auto launch_stack = precision == PNGPD_BF16 ? pngpd::launch_conv_stack_bf16 : pngpd::launch_conv_stack_f32;
-    const StackDev& d = which == 0 ? m->stn : m->trunk;
-    pngpd::ConvStackArgs a = stack_args(d, precision, x_dev, layout, B, P, nullptr, ws.pooled, which == 0);
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(launch_stack(a, s));   // warm
-    HIP_TRY(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) HIP_TRY(launch_stack(a, s));
-    HIP_TRY(hipEventRecord(e1, s));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    *mean_ms_out = ms / iters;
-    return PNGPD_OK;
+int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
+                        int precision, float* logp_dev, float* trans_dev, float* feat_dev,
+                        void* workspace_dev, size_t workspace_bytes, void* stream) {
+    return forward_impl(m, x_dev, layout, B, P, precision, logp_dev, trans_dev, feat_dev, workspace_dev,
+                        workspace_bytes, stream, nullptr);
+}
+
+int pngpd_forward_infer_timed(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
+                              int precision, float* logp_dev, float* trans_dev, float* feat_dev,
+                              void* workspace_dev, size_t workspace_bytes, float* conv_ms_out, void* stream) {
+    if (!conv_ms_out) return fail(PNGPD_ERR_INVALID, "pngpd_forward_infer_timed: NULL conv_ms_out");
+    if (m && !(m->parts & PNGPD_PART_TRUNK)) return fail(PNGPD_ERR_STATE, "pngpd_forward_infer_timed: model has no trunk");
+    hipEvent_t ev[4];
+    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&ev[i]));
+    int rc = forward_impl(m, x_dev, layout, B, P, precision, logp_dev, trans_dev, feat_dev, workspace_dev,
+                          workspace_bytes, stream, ev);
+    if (rc == PNGPD_OK) {
+        hipError_t e = hipEventSynchronize(ev[3]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&conv_ms_out[0], ev[0], ev[1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&conv_ms_out[1], ev[2], ev[3]);
+        if (e != hipSuccess) rc = fail(PNGPD_ERR_HIP, "event timing failed: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
 }
 
 // crop workspace: [G,12] f64 frames, then [G, Wp] u64 mask (frames region rounded up to 256 B)
