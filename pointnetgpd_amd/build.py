@@ -28,6 +28,7 @@ LIB_SOURCES = [
     "crop_grid.hip",
     "voxel.hip",
     "train.hip",
+    "train_conv3.hip",
     "train_api.cpp",
 ]
 

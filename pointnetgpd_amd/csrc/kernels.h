@@ -94,6 +94,8 @@ constexpr int TN_ROWS_PER_CHUNK = 2048;      // rows of one weight-gradient part
 
 int t_red_blocks(int M);                     // row blocks of the column reductions
 int t_tn_chunks(int M);                      // partials of a weight-gradient product
+constexpr int GRAM_ROWS_PER_CHUNK = 1024;    // rows of one Gram-matrix partial (multiple of 32)
+inline int t_gram_chunks(int M) { return (M + GRAM_ROWS_PER_CHUNK - 1) / GRAM_ROWS_PER_CHUNK; }
 
 hipError_t t_points_to_rows(const float* x, const float* trans, float* X3, int B, int P, hipStream_t s);
 hipError_t t_conv1_fwd(const float* X3, const float* W1, const float* b1, float* y1, int M, hipStream_t s);
@@ -104,11 +106,26 @@ hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, co
 hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean, const float* rstd,
                     const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
                     float* dbeta, hipStream_t s);
-hipError_t t_maxpool_bn(const float* y3, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                        int B, int P, int C, int relu, float* pooled, int* arg, hipStream_t s);
-hipError_t t_pool_bwd(float* y3, const float* dpooled, const float* pooled, const int* arg, const float* mean,
-                      const float* rstd, const float* gamma, int B, int P, int C, int relu, float* m1, float* m2,
-                      float* dgamma, float* dbeta, hipStream_t s);
+hipError_t t_col_mean(const float* A, int M, int C, double* part, double* abar_d, hipStream_t s);
+
+// conv3 + BatchNorm (batch statistics) + max over points without the [M,1024] activation (train_conv3.hip)
+struct Conv3Ws {
+    double* abar_d;    // [128] column mean of the input rows
+    double* cov;       // [128,128] covariance of the input rows
+    float* w3p;        // [1024*128] weights scaled by gamma*rstd, packed for the product/max kernel
+    float* sh;         // [1024] shift added after the max
+    float* yh;         // [B,1024] normalised pre-activation at the arg-max row
+    float* gmask;      // [B,1024] pooled gradient after the ReLU mask
+    float* G;          // [128,128] W^T diag(q) W
+    float* ub;         // [128] constant row of the dense input gradient
+};
+hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta, int B,
+                       int P, int relu_out, float momentum, double* part, double* gram_part, const Conv3Ws& w, float* mean,
+                       float* rstd, float* running_mean, float* running_var, float* pooled, int* arg, hipStream_t s);
+hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* dpooled,
+                       const float* pooled, const int* arg, const float* mean, const float* rstd, int B, int P,
+                       int relu_out, const Conv3Ws& w, float* m1, float* m2, float* dW3, float* dgamma, float* dbeta,
+                       float* dh2, hipStream_t s);
 hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s);
 hipError_t t_gemm_tn(const float* dY, const float* Hm, float* part, float* dW, int M, int N, int K, hipStream_t s);
 hipError_t t_conv1_bwd(const float* dy1, const float* X3, const float* W1, int M, double* part, float* dW1,

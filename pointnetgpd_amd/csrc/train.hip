@@ -11,10 +11,9 @@
 // unbiased for running_var, momentum 0.1, eps 1e-5: torch.nn.BatchNorm1d defaults, which the
 // reference keeps, model/pointnet.py:21-25).  Its backward is
 //     dy = gamma*rstd*(g - mean(g) - yhat*mean(g*yhat)),   g = dh*(h > 0)
-// For the 1024-channel layer g is sparse (only the arg-max row of each (candidate, channel)
-// receives gradient from the max-pool), so the two means come from B*1024 values and the dense
-// part of dy is written in place over y.  The bias of a layer that feeds a BatchNorm has an
-// exactly zero gradient (sum_m dy = 0) and is written as 0.
+// The 1024-channel layer with its BatchNorm and max-pool never materialises its [M,1024] output
+// (train_conv3.hip).  The bias of a layer that feeds a BatchNorm has an exactly zero gradient
+// (sum_m dy = 0) and is written as 0.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -195,103 +194,15 @@ __global__ void k_bn_bwd_dense(float* __restrict__ dh, const float* __restrict__
     dh[i] = gamma[c] * rstd[c] * (g - m1[c] - yh * m2[c]);
 }
 
-// ---------------------------------------------------------------------------------------------
-// max-pool over the points of each candidate with BN (+ optional ReLU) applied on the fly
-// pooled[b,c] = max_p act(bn(y3[b,p,c])), arg = first p attaining it (torch max_pool1d rule)
-// block: 256 threads = 64 channels x 4 point lanes; grid (C/64, B)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_maxpool_bn(const float* __restrict__ y3, const float* __restrict__ mean,
-                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, int P, int C, int relu,
-                                                    float* __restrict__ pooled, int* __restrict__ arg) {
-    __shared__ float sv[4][64];
-    __shared__ int si[4][64];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
-    const float sc = rstd[c] * gamma[c], mu = mean[c], be = beta[c];
-    float best = -INFINITY;
-    int bi = 0;
-    for (int p = pl; p < P; p += 4) {
-        const float v = (y3[((size_t)b * P + p) * C + c] - mu) * sc + be;
-        if (v > best) { best = v; bi = p; }
-    }
-    sv[pl][cl] = best;
-    si[pl][cl] = bi;
-    __syncthreads();
-    if (pl == 0) {
-        for (int k = 1; k < 4; ++k) {
-            const float v = sv[k][cl];
-            const int i = si[k][cl];
-            if (v > best || (v == best && i < bi)) { best = v; bi = i; }
-        }
-        pooled[(size_t)b * C + c] = relu ? fmaxf(best, 0.f) : best;
-        arg[(size_t)b * C + c] = bi;
-    }
-}
-
-// sparse BN-backward reductions for the pooled layer: 16 channels x 16 candidate lanes per block
-//   g = dpooled[b,c] * (relu ? pooled[b,c] > 0 : 1); yhat at the arg row
-__global__ __launch_bounds__(256) void k_pool_bwd_reduce(const float* __restrict__ dpooled,
-                                                         const float* __restrict__ pooled,
-                                                         const int* __restrict__ arg, const float* __restrict__ y3,
-                                                         const float* __restrict__ mean,
-                                                         const float* __restrict__ rstd, int B, int P, int C,
-                                                         int relu, float* __restrict__ m1, float* __restrict__ m2,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double sh[2][FIN_LANES][FIN_COLS];
-    const int cl = threadIdx.x & (FIN_COLS - 1), rl = threadIdx.x / FIN_COLS;
-    const int c = blockIdx.x * FIN_COLS + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        const float mu = mean[c], rs = rstd[c];
-        for (int b = rl; b < B; b += FIN_LANES) {
-            float g = dpooled[(size_t)b * C + c];
-            if (relu && !(pooled[(size_t)b * C + c] > 0.f)) g = 0.f;
-            const float yh = (y3[((size_t)b * P + arg[(size_t)b * C + c]) * C + c] - mu) * rs;
-            s1 += (double)g;
-            s2 += (double)(g * yh);
-        }
-    }
-    sh[0][rl][cl] = s1;
-    sh[1][rl][cl] = s2;
-    __syncthreads();
+// Column means of A[M,C] from the mode-0 partials, in double.
+__global__ __launch_bounds__(256) void k_colmean_finalize(const double* __restrict__ part, int nblk,
+                                                          const float* __restrict__ A, int M, int C,
+                                                          double* __restrict__ abar_d) {
+    const int c = blockIdx.x * FIN_COLS + (threadIdx.x & (FIN_COLS - 1)), rl = threadIdx.x / FIN_COLS;
+    double s1, s2;
+    sum_partials2(part, nblk, C, c, rl, s1, s2);
     if (rl != 0 || c >= C) return;
-    s1 = 0.0;
-    s2 = 0.0;
-    for (int k = 0; k < FIN_LANES; ++k) {
-        s1 += sh[0][k][cl];
-        s2 += sh[1][k][cl];
-    }
-    const double M = (double)B * P;
-    m1[c] = (float)(s1 / M);
-    m2[c] = (float)(s2 / M);
-    dgamma[c] = (float)s2;
-    dbeta[c] = (float)s1;
-}
-
-// dense part, in place: y3 <- -gamma*rstd*(m1 + yhat*m2)
-__global__ void k_pool_bwd_dense(float* __restrict__ y3, const float* __restrict__ mean,
-                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                 const float* __restrict__ m1, const float* __restrict__ m2, size_t n, int C) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i % C);
-    const float yh = (y3[i] - mean[c]) * rstd[c];
-    y3[i] = -gamma[c] * rstd[c] * (m1[c] + yh * m2[c]);
-}
-
-// sparse part: dy3[arg row, c] += gamma*rstd*g      (one distinct element per (b,c): no atomics)
-__global__ void k_pool_bwd_sparse(float* __restrict__ dy3, const float* __restrict__ dpooled,
-                                  const float* __restrict__ pooled, const int* __restrict__ arg,
-                                  const float* __restrict__ rstd, const float* __restrict__ gamma, int B, int P,
-                                  int C, int relu) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * C) return;
-    const int c = (int)(i % C);
-    const size_t b = i / C;
-    float g = dpooled[i];
-    if (relu && !(pooled[i] > 0.f)) g = 0.f;
-    dy3[(b * P + arg[i]) * C + c] += gamma[c] * rstd[c] * g;
+    abar_d[c] = (double)A[c] + s1 / M;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -618,22 +529,12 @@ hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean
                        (size_t)M * C, C);
     return hipGetLastError();
 }
-hipError_t t_maxpool_bn(const float* y3, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                        int B, int P, int C, int relu, float* pooled, int* arg, hipStream_t s) {
-    hipLaunchKernelGGL(k_maxpool_bn, dim3(C / 64, B), dim3(256), 0, s, y3, mean, rstd, gamma, beta, P, C, relu, pooled,
-                       arg);
-    return hipGetLastError();
-}
-// y3 (in place) <- dy3 ; also dgamma, dbeta
-hipError_t t_pool_bwd(float* y3, const float* dpooled, const float* pooled, const int* arg, const float* mean,
-                      const float* rstd, const float* gamma, int B, int P, int C, int relu, float* m1, float* m2,
-                      float* dgamma, float* dbeta, hipStream_t s) {
-    hipLaunchKernelGGL(k_pool_bwd_reduce, grid1(C, FIN_COLS), dim3(256), 0, s, dpooled, pooled, arg, (const float*)y3, mean, rstd,
-                       B, P, C, relu, m1, m2, dgamma, dbeta);
-    hipLaunchKernelGGL(k_pool_bwd_dense, grid1((size_t)B * P * C), dim3(256), 0, s, y3, mean, rstd, gamma,
-                       (const float*)m1, (const float*)m2, (size_t)B * P * C, C);
-    hipLaunchKernelGGL(k_pool_bwd_sparse, grid1((size_t)B * C), dim3(256), 0, s, y3, dpooled, pooled, arg, rstd, gamma,
-                       B, P, C, relu);
+hipError_t t_col_mean(const float* A, int M, int C, double* part, double* abar_d, hipStream_t s) {
+    const int nblk = t_red_blocks(M);
+    hipLaunchKernelGGL(k_colreduce, dim3((C + 63) / 64, nblk), dim3(256), 0, s, A, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, 0, part);
+    hipLaunchKernelGGL(k_colmean_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, (const double*)part, nblk, A, M, C,
+                       abar_d);
     return hipGetLastError();
 }
 hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s) {

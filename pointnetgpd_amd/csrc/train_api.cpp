@@ -25,9 +25,10 @@ struct Bump {
 };
 
 struct StackWs {
-    float *X3, *y1, *h1, *y2, *h2, *y3, *pooled, *dh2, *dh1, *dX3;
+    float *X3, *y1, *h1, *y2, *h2, *pooled, *dh2, *dh1, *dX3;
     int* arg;
     float *mean[3], *rstd[3];
+    pngpd::Conv3Ws c3;
 };
 
 struct FcWs {
@@ -39,6 +40,7 @@ struct TrainWs {
     StackWs stn, trunk;
     FcWs stn_fc, head_fc;
     double* part;
+    double* gram_part;
     float *tn_part, *m1, *m2, *dlogits, *dtrans, *trans;
     size_t bytes;
 
@@ -51,7 +53,6 @@ struct TrainWs {
             s->h1 = a.take<float>(M * C1);
             s->y2 = a.take<float>(M * C2);
             s->h2 = a.take<float>(M * C2);
-            s->y3 = a.take<float>(M * C3);
             s->pooled = a.take<float>((size_t)B * C3);
             s->arg = a.take<int>((size_t)B * C3);
             s->dh2 = a.take<float>(M * C2);
@@ -62,6 +63,14 @@ struct TrainWs {
                 s->mean[i] = a.take<float>(ch[i]);
                 s->rstd[i] = a.take<float>(ch[i]);
             }
+            s->c3.abar_d = a.take<double>(C2);
+            s->c3.cov = a.take<double>((size_t)C2 * C2);
+            s->c3.w3p = a.take<float>((size_t)C3 * C2);
+            s->c3.sh = a.take<float>(C3);
+            s->c3.yh = a.take<float>((size_t)B * C3);
+            s->c3.gmask = a.take<float>((size_t)B * C3);
+            s->c3.G = a.take<float>((size_t)C2 * C2);
+            s->c3.ub = a.take<float>(C2);
         }
         for (FcWs* f : {&stn_fc, &head_fc}) {
             f->z1 = a.take<float>((size_t)B * 512);
@@ -79,7 +88,8 @@ struct TrainWs {
         const size_t nblk = (size_t)pngpd::t_red_blocks((int)M);
         part = a.take<double>(nblk * 2 * C3);
         const size_t chunks = (size_t)pngpd::t_tn_chunks((int)M);
-        size_t tn = chunks * (size_t)C3 * C2;
+        gram_part = a.take<double>((size_t)pngpd::t_gram_chunks((int)M) * C2 * C2);
+        size_t tn = chunks * (size_t)C2 * C1;       // conv2 weight-gradient partials
         if (tn < (size_t)512 * 1024) tn = (size_t)512 * 1024;
         tn_part = a.take<float>(tn);
         m1 = a.take<float>(C3);
@@ -121,26 +131,27 @@ int check_shape(int B, int P, int k, const void* ws, size_t ws_bytes) {
 
 // conv1 -> bn -> relu -> conv2 -> bn -> relu -> conv3 -> bn (-> relu) -> max over points
 int fwd_stack(StackWs& S, float* const* p, int u1, const float* x, const float* trans, int B, int P, int relu_out,
-              float momentum, double* part, hipStream_t s) {
+              float momentum, double* part, double* gram_part, hipStream_t s) {
     const int M = B * P;
-    const int ch[3] = {C1, C2, C3};
-    float* ys[3] = {S.y1, S.y2, S.y3};
+    const int ch[2] = {C1, C2};
+    float* ys[2] = {S.y1, S.y2};
     float* hs[2] = {S.h1, S.h2};
     HIP_TRY(pngpd::t_points_to_rows(x, trans, S.X3, B, P, s));
     HIP_TRY(pngpd::t_conv1_fwd(S.X3, slot(p, u1, PNGPD_F_WEIGHT), slot(p, u1, PNGPD_F_BIAS), S.y1, M, s));
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < 2; ++l) {
         const int u = u1 + l;
         if (l > 0)
             HIP_TRY(pngpd::launch_fc_f32(hs[l - 1], slot(p, u, PNGPD_F_WEIGHT), slot(p, u, PNGPD_F_BIAS), ys[l], M,
                                          ch[l], ch[l - 1], 0, s));
         HIP_TRY(pngpd::t_bn_stats(ys[l], M, ch[l], momentum, part, S.mean[l], S.rstd[l], slot(p, u, PNGPD_F_BN_MEAN),
                                   slot(p, u, PNGPD_F_BN_VAR), s));
-        if (l < 2)
-            HIP_TRY(pngpd::t_bn_act_fwd(ys[l], S.mean[l], S.rstd[l], slot(p, u, PNGPD_F_BN_WEIGHT),
-                                        slot(p, u, PNGPD_F_BN_BIAS), hs[l], M, ch[l], 1, s));
+        HIP_TRY(pngpd::t_bn_act_fwd(ys[l], S.mean[l], S.rstd[l], slot(p, u, PNGPD_F_BN_WEIGHT),
+                                    slot(p, u, PNGPD_F_BN_BIAS), hs[l], M, ch[l], 1, s));
     }
-    HIP_TRY(pngpd::t_maxpool_bn(S.y3, S.mean[2], S.rstd[2], slot(p, u1 + 2, PNGPD_F_BN_WEIGHT),
-                                slot(p, u1 + 2, PNGPD_F_BN_BIAS), B, P, C3, relu_out, S.pooled, S.arg, s));
+    const int u3 = u1 + 2;
+    HIP_TRY(pngpd::t_conv3_fwd(S.h2, slot(p, u3, PNGPD_F_WEIGHT), slot(p, u3, PNGPD_F_BIAS), slot(p, u3, PNGPD_F_BN_WEIGHT),
+                               slot(p, u3, PNGPD_F_BN_BIAS), B, P, relu_out, momentum, part, gram_part, S.c3, S.mean[2],
+                               S.rstd[2], slot(p, u3, PNGPD_F_BN_MEAN), slot(p, u3, PNGPD_F_BN_VAR), S.pooled, S.arg, s));
     return PNGPD_OK;
 }
 
@@ -189,13 +200,12 @@ int bwd_fc(FcWs& F, const float* const* p, float* const* g, int u1, const float*
 int bwd_stack(StackWs& S, const float* const* p, float* const* g, int u1, const float* dpooled, int B, int P,
               int relu_out, bool need_dX3, TrainWs& W, hipStream_t s) {
     const int M = B * P;
-    // conv3 / bn3 / max-pool: y3 becomes dy3 in place
-    HIP_TRY(pngpd::t_pool_bwd(S.y3, dpooled, S.pooled, S.arg, S.mean[2], S.rstd[2], cslot(p, u1 + 2, PNGPD_F_BN_WEIGHT), B,
-                              P, C3, relu_out, W.m1, W.m2, slot(g, u1 + 2, PNGPD_F_BN_WEIGHT),
-                              slot(g, u1 + 2, PNGPD_F_BN_BIAS), s));
-    HIP_TRY(pngpd::t_gemm_tn(S.y3, S.h2, W.tn_part, slot(g, u1 + 2, PNGPD_F_WEIGHT), M, C3, C2, s));
+    // conv3 / bn3 / max-pool
+    HIP_TRY(pngpd::t_conv3_bwd(S.h2, cslot(p, u1 + 2, PNGPD_F_WEIGHT), cslot(p, u1 + 2, PNGPD_F_BIAS),
+                               cslot(p, u1 + 2, PNGPD_F_BN_WEIGHT), dpooled, S.pooled, S.arg, S.mean[2], S.rstd[2], B, P,
+                               relu_out, S.c3, W.m1, W.m2, slot(g, u1 + 2, PNGPD_F_WEIGHT),
+                               slot(g, u1 + 2, PNGPD_F_BN_WEIGHT), slot(g, u1 + 2, PNGPD_F_BN_BIAS), S.dh2, s));
     HIP_TRY(pngpd::t_fill(slot(g, u1 + 2, PNGPD_F_BIAS), C3, 0.f, s));
-    HIP_TRY(pngpd::t_gemm_nn(S.y3, cslot(p, u1 + 2, PNGPD_F_WEIGHT), S.dh2, M, C3, C2, s));
     // conv2 / bn2
     HIP_TRY(pngpd::t_bn_bwd(S.dh2, S.h2, S.y2, S.mean[1], S.rstd[1], cslot(p, u1 + 1, PNGPD_F_BN_WEIGHT), M, C2, W.part,
                             W.m1, W.m2, slot(g, u1 + 1, PNGPD_F_BN_WEIGHT), slot(g, u1 + 1, PNGPD_F_BN_BIAS), s));
@@ -232,11 +242,14 @@ int pngpd_train_forward(int B, int P, int k, const float* x_dev, float* const* p
     hipStream_t s = (hipStream_t)stream;
     TrainWs W(workspace_dev, B, P, k);
     float* trans = trans_dev ? trans_dev : W.trans;
-    if ((rc = fwd_stack(W.stn, params_dev, PNGPD_U_STN_CONV1, x_dev, nullptr, B, P, 1, momentum, W.part, s))) return rc;
+    if ((rc = fwd_stack(W.stn, params_dev, PNGPD_U_STN_CONV1, x_dev, nullptr, B, P, 1, momentum, W.part, W.gram_part, s)))
+        return rc;
     if ((rc = fwd_fc(W.stn_fc, params_dev, PNGPD_U_STN_FC1, W.stn.pooled, trans, B, 9, pngpd::FC_TAIL_ADD_IDENTITY,
                      momentum, W.part, s)))
         return rc;
-    if ((rc = fwd_stack(W.trunk, params_dev, PNGPD_U_FEAT_CONV1, x_dev, trans, B, P, 0, momentum, W.part, s))) return rc;
+    if ((rc = fwd_stack(W.trunk, params_dev, PNGPD_U_FEAT_CONV1, x_dev, trans, B, P, 0, momentum, W.part, W.gram_part,
+                       s)))
+        return rc;
     if ((rc = fwd_fc(W.head_fc, params_dev, PNGPD_U_FC1, W.trunk.pooled, logp_dev, B, k, pngpd::FC_TAIL_LOG_SOFTMAX,
                      momentum, W.part, s)))
         return rc;

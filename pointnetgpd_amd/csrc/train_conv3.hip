@@ -1,0 +1,541 @@
+// Training step of the 128 -> 1024 layer with its BatchNorm (batch statistics) and the max over
+// points (conv3 -> bn3 (-> relu) -> MaxPool1d(num_points), model/pointnet.py:32-34 and :146-147,
+// in train() mode, main_1v.py:266-272), without ever holding the [M,1024] activation.
+//
+// With h[M,128] the input rows, w_c the weight row of channel c, abar the column mean of h and
+// Cov = h^T h / M - abar abar^T the 128x128 covariance (one Gram product on the f64 MFMA):
+//   forward   mean_c = w_c.abar + b_c,   var_c = w_c^T Cov w_c   (biased, as BatchNorm normalises)
+//             pooled[b,c] = act(max_p h[b,p,:].(sc_c w_c) + sh_c),  sc = gamma*rstd,
+//             sh = beta - sc*(w_c.abar): the fused product/max kernel of the inference path, on the
+//             exact-f32 MFMA, extended by the arg-max row.
+//   backward  dy[m,c] = A_c g[b,c] [m == arg(b,c)] + p_c + q_c w_c.(h[m,:] - abar)
+//             with g the pooled gradient (masked by the ReLU), m1 = sum g / M, m2 = sum g*yhat_arg / M,
+//             A = gamma*rstd, p = -A m1, q = -A rstd m2.  The dense part is linear in h, so
+//             dh     = h G + ub  (G = W^T diag(q) W, 128x128)  +  rows arg(b,c) += A_c g[b,c] w_c
+//             dW[c,:] = A_c sum_b g[b,c] h[arg(b,c),:] + M (p_c abar + q_c Cov w_c)
+//             dgamma = sum g*yhat_arg, dbeta = sum g.
+// Small reductions run in double, in a fixed order (reproducible).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace pngpd {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr float BN_EPS3 = 1e-5f;
+
+// ---------------------------------------------------------------------------------------------
+// forward: statistics from the Gram matrix, scaled + packed weights
+// ---------------------------------------------------------------------------------------------
+// Gram matrix S = h^T h of the [M,128] input rows on the f64 MFMA (products of floats are exact in double,
+// the sums run in double): partial sums over chunks of GRAM_ROWS_PER_CHUNK rows.
+// grid (3, chunks): 64x64 output blocks (0,0), (0,1), (1,1) - block (1,0) is the transpose of (0,1).
+// v_mfma_f64_16x16x4_f64 lane l: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D reg r = [row (l>>4) + 4r][col l&15].
+typedef __attribute__((ext_vector_type(4))) double f64x4;
+constexpr int GR_LD = 80;       // LDS row stride in floats: the 4 k rows one instruction reads fall on distinct banks
+
+__global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__ A, int M, int rows_per_chunk,
+                                                       double* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float sI[32 * GR_LD];
+    __shared__ __attribute__((aligned(16))) float sJ[32 * GR_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, kq = lane >> 4, wi = wave >> 1, wj = wave & 1;
+    const int i0 = blockIdx.x == 2 ? 64 : 0, j0 = blockIdx.x == 0 ? 0 : 64;
+    const int row_begin = blockIdx.y * rows_per_chunk;
+    const int row_end = min(M, row_begin + rows_per_chunk);
+    const int lrow = tid >> 4, lcol = (tid & 15) * 4;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    float4 va[2], vb[2];
+    auto load_tile = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gm = mb + lrow + 16 * i;
+            const bool ok = gm < row_end;
+            va[i] = ok ? *(const float4*)(A + (size_t)gm * C2 + i0 + lcol) : make_float4(0, 0, 0, 0);
+            vb[i] = ok ? *(const float4*)(A + (size_t)gm * C2 + j0 + lcol) : make_float4(0, 0, 0, 0);
+        }
+    };
+    if (row_begin < row_end) load_tile(row_begin);
+    for (int mb = row_begin; mb < row_end; mb += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(float4*)(sI + (lrow + 16 * i) * GR_LD + lcol) = va[i];
+            *(float4*)(sJ + (lrow + 16 * i) * GR_LD + lcol) = vb[i];
+        }
+        __syncthreads();
+        if (mb + 32 < row_end) load_tile(mb + 32);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float* ri = sI + (4 * s + kq) * GR_LD + wi * 32 + c;
+            const float* rj = sJ + (4 * s + kq) * GR_LD + wj * 32 + c;
+            const double a0 = (double)ri[0], a1 = (double)ri[16];
+            const double b0 = (double)rj[0], b1 = (double)rj[16];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    double* out = part + (size_t)blockIdx.y * C2 * C2;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wi * 32 + 16 * a + kq + 4 * r, j = j0 + wj * 32 + 16 * b + c;
+                out[(size_t)i * C2 + j] = acc[a][b][r];
+            }
+}
+
+// cov[i][j] = sum_chunks S_chunk[i][j] / M - abar_i abar_j   (fixed order over the chunks)
+__global__ void k_gram_finalize(const double* __restrict__ part, int chunks, const double* __restrict__ abar_d, int M,
+                                double* __restrict__ cov) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C2 * C2) return;
+    const int i = idx / C2, j = idx - i * C2;
+    const int src = (i >= 64 && j < 64) ? j * C2 + i : idx;      // the block that was not computed: by symmetry
+    double s = 0.0;
+    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * C2 * C2 + src];
+    cov[idx] = s / M - abar_d[i] * abar_d[j];
+}
+
+// Index of W3[c][k] in the packed image the product/max kernel streams (32x32x2 fragments, same element
+// order as the inference image): lane half hh of step (t, g, e) holds k = 32t + 8g + 4hh + e.
+__device__ __forceinline__ int w3p_index(int c, int k) {
+    const int nt = c >> 5, r = c & 31, t = k >> 5, rem = k & 31;
+    const int g = rem >> 3, hh = (rem >> 2) & 1, e = rem & 3;
+    return (((nt * 16 + 4 * t + g) * 64) + r + 32 * hh) * 4 + e;
+}
+
+// one block of 128 threads per channel
+__global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restrict__ W3, const float* __restrict__ b3,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const double* __restrict__ cov,
+                                                          const double* __restrict__ abar_d, int M, float momentum,
+                                                          float* __restrict__ mean, float* __restrict__ rstd,
+                                                          float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ w3p,
+                                                          float* __restrict__ sh) {
+    __shared__ double s_w[C2], s_q[C2], s_m[C2];
+    __shared__ float s_sc;
+    const int c = blockIdx.x, i = threadIdx.x;
+    const float wf = W3[(size_t)c * C2 + i];
+    s_w[i] = (double)wf;
+    __syncthreads();
+    double t = 0.0;
+    for (int j = 0; j < C2; ++j) t += cov[(size_t)j * C2 + i] * s_w[j];    // Cov is symmetric: coalesced over i
+    s_q[i] = t * (double)wf;
+    s_m[i] = abar_d[i] * (double)wf;
+    __syncthreads();
+    if (i == 0) {
+        double var = 0.0, wa = 0.0;
+        for (int j = 0; j < C2; ++j) {
+            var += s_q[j];
+            wa += s_m[j];
+        }
+        if (var < 0.0) var = 0.0;
+        const double mu = wa + (double)b3[c];
+        const double rs = 1.0 / sqrt(var + (double)BN_EPS3);
+        mean[c] = (float)mu;
+        rstd[c] = (float)rs;
+        if (running_mean != nullptr) {
+            const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+        }
+        const float sc = (float)rs * gamma[c];
+        s_sc = sc;
+        sh[c] = (float)((double)beta[c] - (double)sc * wa);
+    }
+    __syncthreads();
+    w3p[w3p_index(c, i)] = wf * s_sc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: pooled[b,c] = act(max_p h[b,p,:].w'_c + sh_c), arg = first p attaining the maximum
+// grid (B, CS): a workgroup of 4 waves handles 1024/CS channels of one candidate; every wave takes
+// 64 points per pass (two 32-point tiles as MFMA A operands, read straight from the rows of h) and
+// sweeps the block's channel tiles, whose weights stream through a double-buffered 8 KiB LDS chunk.
+// ---------------------------------------------------------------------------------------------
+constexpr int TC_WAVES = 4, TC_THREADS = 256, TC_MT = 2;
+constexpr int TC_CHUNK_BYTES = 8192;     // half a 32-channel tile: 64 k values x 32 channels
+
+__device__ __forceinline__ void tc_dma_chunk(const char* src, char* dst, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = wave * 2 + i;
+        __builtin_amdgcn_global_load_lds((const void*)(src + piece * 1024 + lane * 16), (lds_void*)(dst + piece * 1024),
+                                         16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(TC_THREADS, 2) void conv3_pool_train_kernel(const float* __restrict__ h,
+                                                                         const float* __restrict__ w3p,
+                                                                         const float* __restrict__ sh, int P, int relu,
+                                                                         int ntb, float* __restrict__ pooled,
+                                                                         int* __restrict__ arg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.x, nt0 = blockIdx.y * ntb;
+    const int nch = 32 * ntb, nchunks = 2 * ntb;
+    char* s_w3 = smem;
+    float* s_red = (float*)(smem + 2 * TC_CHUNK_BYTES);      // [4][nch]
+    int* s_arg = (int*)(s_red + TC_WAVES * nch);             // [4][nch]
+    const char* g_w3 = (const char*)w3p + (size_t)(2 * nt0) * TC_CHUNK_BYTES;
+
+    tc_dma_chunk(g_w3, s_w3, wave, lane);
+    for (int c = tid; c < TC_WAVES * nch; c += TC_THREADS) {
+        s_red[c] = -INFINITY;
+        s_arg[c] = 0;
+    }
+    __syncthreads();
+
+    float* s_red_wave = s_red + wave * nch;
+    int* s_arg_wave = s_arg + wave * nch;
+    const int pts_per_pass = TC_WAVES * 32 * TC_MT;
+    const int npass = (P + pts_per_pass - 1) / pts_per_pass;
+
+    for (int pass = 0; pass < npass; ++pass) {
+        // A operands: X[mt][t] register 4g+e holds k = 32t + 8g + 4hh + e of point r of tile mt
+        f32x16 X[TC_MT][4];
+        const int pt_base = pass * pts_per_pass + wave * TC_MT * 32;
+#pragma unroll
+        for (int mt = 0; mt < TC_MT; ++mt) {
+            int pt = pt_base + mt * 32 + r;
+            pt = pt < P ? pt : P - 1;                       // duplicates of the last point cannot change a maximum
+            const float* hp = h + ((size_t)b * P + pt) * C2 + 4 * hh;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = *(const f32x4*)(hp + 32 * t + 8 * g);
+                    X[mt][t][4 * g + 0] = v[0];
+                    X[mt][t][4 * g + 1] = v[1];
+                    X[mt][t][4 * g + 2] = v[2];
+                    X[mt][t][4 * g + 3] = v[3];
+                }
+        }
+        const bool last_pass = (pass == npass - 1);
+        for (int nt = 0; nt < ntb; ++nt) {
+            f32x16 acc[TC_MT];
+#pragma unroll
+            for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = f32x16{0};
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int ck = 2 * nt + half;
+                if (!(last_pass && ck == nchunks - 1)) {
+                    const int nxt = ck + 1 < nchunks ? ck + 1 : 0;
+                    tc_dma_chunk(g_w3 + (size_t)nxt * TC_CHUNK_BYTES, s_w3 + ((half + 1) & 1) * TC_CHUNK_BYTES, wave,
+                                 lane);
+                }
+                const char* buf = s_w3 + half * TC_CHUNK_BYTES;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f32x4 bw = *(const f32x4*)(buf + (q * 64 + lane) * 16);
+                    const int t = 2 * half + (q >> 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mt = 0; mt < TC_MT; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X[mt][t][4 * (q & 3) + e], bw[e], acc[mt], 0,
+                                                                          0, 0);
+                }
+                __syncthreads();
+            }
+            // accumulator register i of lane half hh is point (i&3) + 8(i>>2) + 4hh of the tile, channel 32nt + r:
+            // ascending i is ascending point index, so a strict compare keeps the first maximum
+            float bv = -INFINITY;
+            int bi = 0;
+#pragma unroll
+            for (int mt = 0; mt < TC_MT; ++mt) {
+                const int base = pt_base + mt * 32 + 4 * hh;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = acc[mt][i];
+                    const int idx = base + (i & 3) + 8 * (i >> 2);
+                    if (v > bv) {
+                        bv = v;
+                        bi = idx;
+                    }
+                }
+            }
+            bi = bi < P ? bi : P - 1;
+            const float ov = __shfl_xor(bv, 32);
+            const int oi = __shfl_xor(bi, 32);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+            if (hh == 0 && bv > s_red_wave[32 * nt + r]) {   // later passes hold later points: strict compare
+                s_red_wave[32 * nt + r] = bv;
+                s_arg_wave[32 * nt + r] = bi;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < nch; c += TC_THREADS) {
+        float bv = s_red[c];
+        int bi = s_arg[c];
+#pragma unroll
+        for (int w = 1; w < TC_WAVES; ++w) {
+            const float v = s_red[w * nch + c];
+            const int i = s_arg[w * nch + c];
+            if (v > bv || (v == bv && i < bi)) {
+                bv = v;
+                bi = i;
+            }
+        }
+        const int ch = 32 * nt0 + c;
+        bv += sh[ch];
+        pooled[(size_t)b * C3 + ch] = relu ? __builtin_fmaxf(bv, 0.f) : bv;
+        arg[(size_t)b * C3 + ch] = bi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+// One wave per (b, c): yhat at the arg-max row, recomputed as a 128-term product; also the masked pooled
+// gradient.  block = 4 waves x 16 consecutive channels each.
+__global__ __launch_bounds__(256) void k_conv3_arg_yhat(const float* __restrict__ h, const float* __restrict__ W3,
+                                                        const float* __restrict__ b3, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd,
+                                                        const float* __restrict__ dpooled,
+                                                        const float* __restrict__ pooled, const int* __restrict__ arg,
+                                                        int B, int P, int relu, float* __restrict__ yh,
+                                                        float* __restrict__ gmask) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t first = ((size_t)blockIdx.x * 4 + wave) * 16;
+    if (first >= (size_t)B * C3) return;
+    const int b = (int)(first / C3), c0 = (int)(first - (size_t)b * C3);
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        const int c = c0 + j;
+        const int row = arg[(size_t)b * C3 + c];
+        const float2 hv = *(const float2*)(h + ((size_t)b * P + row) * C2 + 2 * lane);
+        const float2 wv = *(const float2*)(W3 + (size_t)c * C2 + 2 * lane);
+        float d = fmaf(hv.x, wv.x, hv.y * wv.y);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off);
+        if (lane == 0) {
+            const size_t o = (size_t)b * C3 + c;
+            yh[o] = (d + b3[c] - mean[c]) * rstd[c];
+            float g = dpooled[o];
+            if (relu && !(pooled[o] > 0.f)) g = 0.f;
+            gmask[o] = g;
+        }
+    }
+}
+
+// m1 = sum_b g / M, m2 = sum_b g*yhat / M, dgamma = sum g*yhat, dbeta = sum g; 16 channels x 16 candidate lanes
+__global__ __launch_bounds__(256) void k_conv3_bwd_reduce(const float* __restrict__ gmask, const float* __restrict__ yh,
+                                                          int B, int P, float* __restrict__ m1, float* __restrict__ m2,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double shm[2][16][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = rl; b < B; b += 16) {
+        const float g = gmask[(size_t)b * C3 + c];
+        s1 += (double)g;
+        s2 += (double)(g * yh[(size_t)b * C3 + c]);
+    }
+    shm[0][rl][cl] = s1;
+    shm[1][rl][cl] = s2;
+    __syncthreads();
+    if (rl != 0) return;
+    s1 = 0.0;
+    s2 = 0.0;
+    for (int k = 0; k < 16; ++k) {
+        s1 += shm[0][k][cl];
+        s2 += shm[1][k][cl];
+    }
+    const double M = (double)B * P;
+    m1[c] = (float)(s1 / M);
+    m2[c] = (float)(s2 / M);
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+}
+
+// G[i][k] = sum_c q_c W[c,i] W[c,k] (blocks 0..127 = i), ub[k] = sum_c (p_c - q_c (mean_c - b_c)) W[c,k] (block 128)
+__global__ __launch_bounds__(128) void k_conv3_bwd_G(const float* __restrict__ W3, const float* __restrict__ b3,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ m1,
+                                                     const float* __restrict__ m2, float* __restrict__ G,
+                                                     float* __restrict__ ub) {
+    __shared__ double s_f[C3];
+    const int i = blockIdx.x, k = threadIdx.x;
+    for (int c = k; c < C3; c += 128) {
+        const double A = (double)gamma[c] * (double)rstd[c];
+        const double q = -A * (double)rstd[c] * (double)m2[c];
+        if (i < C2)
+            s_f[c] = q * (double)W3[(size_t)c * C2 + i];
+        else
+            s_f[c] = -A * (double)m1[c] - q * ((double)mean[c] - (double)b3[c]);
+    }
+    __syncthreads();
+    double acc = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < C3; ++c) acc += s_f[c] * (double)W3[(size_t)c * C2 + k];
+    if (i < C2)
+        G[(size_t)i * C2 + k] = (float)acc;
+    else
+        ub[k] = (float)acc;
+}
+
+// Rows that hold a maximum: dh[b*P + arg(b,c), :] += A_c g[b,c] W[c,:].  One workgroup of 16 waves per
+// candidate: the 1024 channels are sorted by (arg row, channel) with a rank count, wave w owns the rows
+// [w*ceil(P/16), ...) - a contiguous piece of the sorted list - and adds up each of its rows in channel
+// order before a single read-modify-write (no atomics, fixed order).
+__global__ __launch_bounds__(1024) void k_conv3_sparse_dgrad(const float* __restrict__ W3, const float* __restrict__ gamma,
+                                                             const float* __restrict__ rstd,
+                                                             const float* __restrict__ gmask,
+                                                             const int* __restrict__ arg, int P,
+                                                             float* __restrict__ dh) {
+    __shared__ int s_row[C3];
+    __shared__ float s_coef[C3];
+    __shared__ short s_list[C3];
+    const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    const int my = arg[(size_t)b * C3 + c];
+    s_row[c] = my;
+    s_coef[c] = gamma[c] * rstd[c] * gmask[(size_t)b * C3 + c];
+    __syncthreads();
+    int rank = 0;
+#pragma unroll 8
+    for (int o = 0; o < C3; ++o) {
+        const int a = s_row[o];
+        rank += (a < my || (a == my && o < c)) ? 1 : 0;
+    }
+    s_list[rank] = (short)c;
+    __syncthreads();
+    const int rows_per_wave = (P + 15) / 16;
+    const int row_lo = wave * rows_per_wave, row_hi = min(P, row_lo + rows_per_wave);
+    // first sorted position whose row is >= row_lo
+    int lo = 0, hi = C3;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (s_row[s_list[mid]] < row_lo) lo = mid + 1; else hi = mid;
+    }
+    int pos = lo;
+    while (pos < C3) {
+        const int row = s_row[s_list[pos]];
+        if (row >= row_hi) break;
+        float2 acc = make_float2(0.f, 0.f);
+        while (pos < C3) {
+            const int ch = s_list[pos];
+            if (s_row[ch] != row) break;
+            const float cf = s_coef[ch];
+            const float2 w = *(const float2*)(W3 + (size_t)ch * C2 + 2 * lane);
+            acc.x = fmaf(cf, w.x, acc.x);
+            acc.y = fmaf(cf, w.y, acc.y);
+            ++pos;
+        }
+        float2* out = (float2*)(dh + ((size_t)b * P + row) * C2 + 2 * lane);
+        float2 v = *out;
+        v.x += acc.x;
+        v.y += acc.y;
+        *out = v;
+    }
+}
+
+// dW[c,j] = A_c sum_b g[b,c] h[arg(b,c), j] + M (p_c abar_j + q_c sum_i W[c,i] Cov[i][j]); block per channel
+__global__ __launch_bounds__(128) void k_conv3_wgrad(const float* __restrict__ h, const float* __restrict__ W3,
+                                                     const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                     const float* __restrict__ m1, const float* __restrict__ m2,
+                                                     const float* __restrict__ gmask, const int* __restrict__ arg,
+                                                     const double* __restrict__ cov, const double* __restrict__ abar_d,
+                                                     int B, int P, float* __restrict__ dW) {
+    __shared__ float s_g[128];
+    __shared__ int s_r[128];
+    __shared__ double s_w[C2];
+    const int c = blockIdx.x, j = threadIdx.x;
+    s_w[j] = (double)W3[(size_t)c * C2 + j];
+    double sparse = 0.0;
+    for (int b0 = 0; b0 < B; b0 += 128) {
+        __syncthreads();
+        const int bb = b0 + j;
+        if (bb < B) {
+            s_g[j] = gmask[(size_t)bb * C3 + c];
+            s_r[j] = bb * P + arg[(size_t)bb * C3 + c];
+        }
+        __syncthreads();
+        const int n = min(128, B - b0);
+        float acc = 0.f;
+#pragma unroll 8
+        for (int t = 0; t < n; ++t) acc = fmaf(s_g[t], h[(size_t)s_r[t] * C2 + j], acc);
+        sparse += (double)acc;
+    }
+    __syncthreads();
+    double dense = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < C2; ++i) dense += s_w[i] * cov[(size_t)i * C2 + j];
+    const double M = (double)B * P;
+    const double A = (double)gamma[c] * (double)rstd[c];
+    const double p = -A * (double)m1[c], q = -A * (double)rstd[c] * (double)m2[c];
+    dW[(size_t)c * C2 + j] = (float)(A * sparse + M * (p * abar_d[j] + q * dense));
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------
+hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta, int B,
+                       int P, int relu_out, float momentum, double* part, double* gram_part, const Conv3Ws& w, float* mean,
+                       float* rstd, float* running_mean, float* running_var, float* pooled, int* arg, hipStream_t s) {
+    const int M = B * P;
+    hipError_t e = t_col_mean(h2, M, C2, part, w.abar_d, s);
+    if (e != hipSuccess) return e;
+    const int chunks = t_gram_chunks(M);
+    hipLaunchKernelGGL(gram_f64_kernel, dim3(3, chunks), dim3(256), 0, s, h2, M, GRAM_ROWS_PER_CHUNK, gram_part);
+    hipLaunchKernelGGL(k_gram_finalize, dim3(C2 * C2 / 256), dim3(256), 0, s, (const double*)gram_part, chunks,
+                       (const double*)w.abar_d, M, w.cov);
+    hipLaunchKernelGGL(k_conv3_stats_pack, dim3(C3), dim3(128), 0, s, W3, b3, gamma, beta, (const double*)w.cov,
+                       (const double*)w.abar_d, M, momentum, mean, rstd, running_mean, running_var, w.w3p, w.sh);
+    // enough workgroups for two per CU: split the channels of a candidate when the batch is small
+    int dev = 0, n_cu = 0;
+    e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    int cs = 1;
+    while (cs < 8 && B * cs < 2 * n_cu) cs *= 2;
+    const int ntb = 32 / cs;
+    const size_t lds = 2 * TC_CHUNK_BYTES + (size_t)TC_WAVES * 32 * ntb * 8;
+    e = hipFuncSetAttribute((const void*)conv3_pool_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv3_pool_train_kernel, dim3(B, cs), dim3(TC_THREADS), lds, s, h2, (const float*)w.w3p,
+                       (const float*)w.sh, P, relu_out, ntb, pooled, arg);
+    return hipGetLastError();
+}
+
+hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* dpooled,
+                       const float* pooled, const int* arg, const float* mean, const float* rstd, int B, int P,
+                       int relu_out, const Conv3Ws& w, float* m1, float* m2, float* dW3, float* dgamma, float* dbeta,
+                       float* dh2, hipStream_t s) {
+    const int M = B * P;
+    hipLaunchKernelGGL(k_conv3_arg_yhat, dim3((unsigned)(((size_t)B * C3 + 63) / 64)), dim3(256), 0, s, h2, W3, b3, mean,
+                       rstd, dpooled, pooled, arg, B, P, relu_out, w.yh, w.gmask);
+    hipLaunchKernelGGL(k_conv3_bwd_reduce, dim3(C3 / 16), dim3(256), 0, s, (const float*)w.gmask, (const float*)w.yh, B,
+                       P, m1, m2, dgamma, dbeta);
+    hipLaunchKernelGGL(k_conv3_bwd_G, dim3(C2 + 1), dim3(128), 0, s, W3, b3, gamma, mean, rstd, (const float*)m1,
+                       (const float*)m2, w.G, w.ub);
+    hipError_t e = launch_fc_f32(h2, w.G, w.ub, dh2, M, C2, C2, 0, s);     // G is symmetric: h G = h G^T
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_conv3_sparse_dgrad, dim3(B), dim3(1024), 0, s, W3, gamma, rstd, (const float*)w.gmask, arg, P,
+                       dh2);
+    hipLaunchKernelGGL(k_conv3_wgrad, dim3(C3), dim3(128), 0, s, h2, W3, gamma, rstd, (const float*)m1, (const float*)m2,
+                       (const float*)w.gmask, arg, (const double*)w.cov, (const double*)w.abar_d, B, P, dW3);
+    return hipGetLastError();
+}
+
+}  // namespace pngpd

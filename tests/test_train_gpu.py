@@ -169,3 +169,31 @@ def test_every_gradient_against_oracle():
     for n in ref_sd:
         if n.endswith(("running_mean", "running_var")):
             np.testing.assert_allclose(got_sd[n].cpu().numpy(), ref_sd[n].numpy(), rtol=2e-4, atol=2e-5, err_msg=n)
+
+
+@pytest.mark.parametrize("P,B,k,seed", [(5, 16, 2, 5), (40, 8, 3, 6), (257, 9, 2, 7), (130, 70, 2, 8)])
+def test_gradients_and_statistics_at_odd_shapes(P, B, k, seed):
+    """Shapes that leave point tiles, channel splits and per-wave row ranges of the conv3 path partly empty."""
+    gain = 1.3
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
+    target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) * k).astype(np.int64))
+    sd = synth.torch_state_dict(seed, k, 1.0, gain)
+    oracle = po.build_cls(P, k, sd, eval_mode=False)
+    out, trans = oracle(x)
+    F.nll_loss(out, target).backward()
+    m = hip_train_model(P, k, seed, gain)
+    out2, trans2 = m(x.cuda())
+    F.nll_loss(out2, target.cuda()).backward()
+    np.testing.assert_allclose(out2.detach().cpu().numpy(), out.detach().numpy(), atol=1e-4)
+    np.testing.assert_allclose(trans2.detach().cpu().numpy(), trans.detach().numpy(), atol=1e-4)
+    ref = {n: p.grad.numpy() for n, p in oracle.named_parameters()}
+    for n, p in m.named_parameters():
+        g = p.grad.cpu().numpy()
+        if np.abs(ref[n]).max() < 1e-5:
+            assert np.abs(g).max() < 1e-5, n
+        else:
+            assert rel_err(g, ref[n]) < 3e-3, (n, rel_err(g, ref[n]))
+    ref_sd, got_sd = oracle.state_dict(), m.state_dict()
+    for n in ref_sd:
+        if n.endswith(("running_mean", "running_var")):
+            np.testing.assert_allclose(got_sd[n].cpu().numpy(), ref_sd[n].numpy(), rtol=2e-4, atol=2e-5, err_msg=n)
