@@ -65,41 +65,67 @@ __global__ void k_conv1_fwd(const float* __restrict__ X3, const float* __restric
 // ---------------------------------------------------------------------------------------------
 constexpr int RED_ROWS = 256;   // rows per block
 
+// block = 256 threads = QB column quads (float4) x RL row lanes, QB = min(C/4, 64); grid = (ceil(C/4/QB), ceil(M/RED_ROWS))
 __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ A, const float* __restrict__ H,
                                                    const float* __restrict__ Y, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, int M, int C, int mode,
                                                    double* __restrict__ part) {
-    // block = 256 threads = 64 columns x 4 row lanes; grid = (ceil(C/64), ceil(M/RED_ROWS))
-    __shared__ double s1s[4][64], s2s[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double red[2][256 * 4];       // [s1|s2][row lane][column of the block]
+    const int cq = C >> 2;
+    const int QB = cq < 64 ? cq : 64, RL = 256 / QB;
+    const int ql = threadIdx.x % QB, rl = threadIdx.x / QB;
+    const int q = blockIdx.x * QB + ql;      // column quad
     const int r0 = blockIdx.y * RED_ROWS;
     const int r1 = min(M, r0 + RED_ROWS);
-    float s1 = 0.f, s2 = 0.f;
-    if (c < C) {
+    float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+    if (q < cq && rl < RL) {
+        const size_t col = (size_t)q * 4;
         if (mode == 0) {
-            const float a0 = A[c];
-            for (int r = r0 + rl; r < r1; r += 4) {
-                const float d = A[(size_t)r * C + c] - a0;
-                s1 += d;
-                s2 += d * d;
+            const float4 a0 = *(const float4*)(A + col);
+#pragma unroll 4
+            for (int r = r0 + rl; r < r1; r += RL) {
+                const float4 a = *(const float4*)(A + (size_t)r * C + col);
+                const float dx = a.x - a0.x, dy = a.y - a0.y, dz = a.z - a0.z, dw = a.w - a0.w;
+                s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+                s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
             }
         } else {
-            const float mu = mean[c], rs = rstd[c];
-            for (int r = r0 + rl; r < r1; r += 4) {
-                float g = A[(size_t)r * C + c];
-                if (H != nullptr && !(H[(size_t)r * C + c] > 0.f)) g = 0.f;
-                s1 += g;
-                s2 += g * ((Y[(size_t)r * C + c] - mu) * rs);
+            const float4 mu = *(const float4*)(mean + col), rs = *(const float4*)(rstd + col);
+#pragma unroll 4
+            for (int r = r0 + rl; r < r1; r += RL) {
+                float4 g = *(const float4*)(A + (size_t)r * C + col);
+                const float4 y = *(const float4*)(Y + (size_t)r * C + col);
+                if (H != nullptr) {
+                    const float4 hv = *(const float4*)(H + (size_t)r * C + col);
+                    if (!(hv.x > 0.f)) g.x = 0.f;
+                    if (!(hv.y > 0.f)) g.y = 0.f;
+                    if (!(hv.z > 0.f)) g.z = 0.f;
+                    if (!(hv.w > 0.f)) g.w = 0.f;
+                }
+                s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+                s2.x += g.x * ((y.x - mu.x) * rs.x);
+                s2.y += g.y * ((y.y - mu.y) * rs.y);
+                s2.z += g.z * ((y.z - mu.z) * rs.z);
+                s2.w += g.w * ((y.w - mu.w) * rs.w);
             }
         }
     }
-    s1s[rl][cl] = (double)s1;
-    s2s[rl][cl] = (double)s2;
+    if (rl < RL) {
+        double* d1 = red[0] + (rl * QB + ql) * 4;
+        double* d2 = red[1] + (rl * QB + ql) * 4;
+        d1[0] = (double)s1.x; d1[1] = (double)s1.y; d1[2] = (double)s1.z; d1[3] = (double)s1.w;
+        d2[0] = (double)s2.x; d2[1] = (double)s2.y; d2[2] = (double)s2.z; d2[3] = (double)s2.w;
+    }
     __syncthreads();
-    if (rl == 0 && c < C) {
-        const double a = s1s[0][cl] + s1s[1][cl] + s1s[2][cl] + s1s[3][cl];
-        const double b = s2s[0][cl] + s2s[1][cl] + s2s[2][cl] + s2s[3][cl];
+    const int ncol = QB * 4;
+    for (int t = threadIdx.x; t < ncol; t += 256) {
+        const int c = blockIdx.x * ncol + t;
+        if (c >= C) continue;
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < RL; ++k) {          // fixed order: reproducible
+            a += red[0][k * ncol + t];
+            b += red[1][k * ncol + t];
+        }
         part[((size_t)blockIdx.y * 2 + 0) * C + c] = a;
         part[((size_t)blockIdx.y * 2 + 1) * C + c] = b;
     }
@@ -420,20 +446,36 @@ __global__ void k_small_dgrad(const float* __restrict__ dZ, const float* __restr
     dA[i] = s;
 }
 
-// dW[n,k] = sum_m dZ[m,n] A[m,k];  db[n] = sum_m dZ[m,n]     (thread per (n,k); M = batch)
-__global__ void k_small_wgrad(const float* __restrict__ dZ, const float* __restrict__ A, float* __restrict__ dW,
-                              float* __restrict__ db, int M, int N, int K) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * K) return;
-    const int k = i % K, n = i / K;
-    float s = 0.f, sb = 0.f;
-    for (int m = 0; m < M; ++m) {
-        const float g = dZ[(size_t)m * N + n];
-        s += g * A[(size_t)m * K + k];
-        sb += g;
+// dW[n,k] = sum_m dZ[m,n] A[m,k];  db[n] = sum_m dZ[m,n]     (M = batch)
+// block = 16 k x 16 row lanes, grid (K/16, N): every row lane sums every 16th row, the lane sums are added in a
+// fixed order
+__global__ __launch_bounds__(256) void k_small_wgrad(const float* __restrict__ dZ, const float* __restrict__ A,
+                                                     float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                     int K) {
+    __shared__ float sw[16][16], sb[16];
+    const int kl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + kl, n = blockIdx.y;
+    float s = 0.f, b = 0.f;
+    if (k < K) {
+#pragma unroll 4
+        for (int m = rl; m < M; m += 16) {
+            const float g = dZ[(size_t)m * N + n];
+            s = fmaf(g, A[(size_t)m * K + k], s);
+            b += g;
+        }
     }
-    dW[i] = s;
-    if (k == 0) db[n] = sb;
+    sw[rl][kl] = s;
+    if (kl == 0) sb[rl] = b;
+    __syncthreads();
+    if (rl != 0) return;
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += sw[i][kl];
+    if (k < K) dW[(size_t)n * K + k] = t;
+    if (blockIdx.x == 0 && kl == 0) {
+        float u = 0.f;
+        for (int i = 0; i < 16; ++i) u += sb[i];
+        db[n] = u;
+    }
 }
 
 // db[n] = sum_m dY[m,n] for layers WITHOUT a following BatchNorm is handled by k_small_wgrad;
@@ -490,6 +532,7 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 // ---------------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------------
+static inline int colreduce_grid_x(int C) { return (C / 4 + 63) / 64; }   // blocks of up to 64 column quads
 static inline dim3 grid1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 hipError_t t_points_to_rows(const float* x, const float* trans, float* X3, int B, int P, hipStream_t s) {
@@ -505,7 +548,7 @@ int t_red_blocks(int M) { return (M + RED_ROWS - 1) / RED_ROWS; }
 hipError_t t_bn_stats(const float* A, int M, int C, float momentum, double* part, float* mean, float* rstd,
                       float* running_mean, float* running_var, hipStream_t s) {
     const int nblk = t_red_blocks(M);
-    hipLaunchKernelGGL(k_colreduce, dim3((C + 63) / 64, nblk), dim3(256), 0, s, A, (const float*)nullptr,
+    hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, A, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, 0, part);
     hipLaunchKernelGGL(k_stats_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, A, M, C, momentum, mean, rstd,
                        running_mean, running_var);
@@ -522,7 +565,7 @@ hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean
                     const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
                     float* dbeta, hipStream_t s) {
     const int nblk = t_red_blocks(M);
-    hipLaunchKernelGGL(k_colreduce, dim3((C + 63) / 64, nblk), dim3(256), 0, s, (const float*)dh, h, y, mean, rstd, M,
+    hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, (const float*)dh, h, y, mean, rstd, M,
                        C, 1, part);
     hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta);
     hipLaunchKernelGGL(k_bn_bwd_dense, grid1((size_t)M * C), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, m1, m2,
@@ -531,7 +574,7 @@ hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean
 }
 hipError_t t_col_mean(const float* A, int M, int C, double* part, double* abar_d, hipStream_t s) {
     const int nblk = t_red_blocks(M);
-    hipLaunchKernelGGL(k_colreduce, dim3((C + 63) / 64, nblk), dim3(256), 0, s, A, (const float*)nullptr,
+    hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, A, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, 0, part);
     hipLaunchKernelGGL(k_colmean_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, (const double*)part, nblk, A, M, C,
                        abar_d);
@@ -569,7 +612,7 @@ hipError_t t_trans_grad(const float* x, const float* dX3, int B, int P, const fl
 hipError_t t_small_bwd(const float* dZ, const float* A, const float* W, float* dA, float* dW, float* db, int M, int N,
                        int K, hipStream_t s) {
     hipLaunchKernelGGL(k_small_dgrad, grid1((size_t)M * K), dim3(256), 0, s, dZ, W, dA, M, N, K);
-    hipLaunchKernelGGL(k_small_wgrad, grid1((size_t)N * K), dim3(256), 0, s, dZ, A, dW, db, M, N, K);
+    hipLaunchKernelGGL(k_small_wgrad, dim3((K + 15) / 16, N), dim3(256), 0, s, dZ, A, dW, db, M, N, K);
     return hipGetLastError();
 }
 hipError_t t_fill(float* p, size_t n, float v, hipStream_t s) {

@@ -96,15 +96,23 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__
             }
 }
 
-// cov[i][j] = sum_chunks S_chunk[i][j] / M - abar_i abar_j   (fixed order over the chunks)
-__global__ void k_gram_finalize(const double* __restrict__ part, int chunks, const double* __restrict__ abar_d, int M,
-                                double* __restrict__ cov) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= C2 * C2) return;
+// cov[i][j] = sum_chunks S_chunk[i][j] / M - abar_i abar_j.  block = 16 elements x 16 chunk lanes: a lane sums every
+// 16th chunk, the lane sums are added in a fixed order.
+__global__ __launch_bounds__(256) void k_gram_finalize(const double* __restrict__ part, int chunks,
+                                                       const double* __restrict__ abar_d, int M,
+                                                       double* __restrict__ cov) {
+    __shared__ double sh[16][16];
+    const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + el;
     const int i = idx / C2, j = idx - i * C2;
     const int src = (i >= 64 && j < 64) ? j * C2 + i : idx;      // the block that was not computed: by symmetry
     double s = 0.0;
-    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * C2 * C2 + src];
+    for (int c = rl; c < chunks; c += 16) s += part[(size_t)c * C2 * C2 + src];
+    sh[rl][el] = s;
+    __syncthreads();
+    if (rl != 0) return;
+    s = 0.0;
+    for (int k = 0; k < 16; ++k) s += sh[k][el];
     cov[idx] = s / M - abar_d[i] * abar_d[j];
 }
 
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(128) void k_conv3_bwd_G(const float* __restrict__ W
 // Rows that hold a maximum: dh[b*P + arg(b,c), :] += A_c g[b,c] W[c,:].  One workgroup of 16 waves per
 // candidate: the 1024 channels are sorted by (arg row, channel) with a rank count, wave w owns the rows
 // [w*ceil(P/16), ...) - a contiguous piece of the sorted list - and adds up each of its rows in channel
-// order before a single read-modify-write (no atomics, fixed order).
+// order before it is added to the row once (fixed order).
 __global__ __launch_bounds__(1024) void k_conv3_sparse_dgrad(const float* __restrict__ W3, const float* __restrict__ gamma,
                                                              const float* __restrict__ rstd,
                                                              const float* __restrict__ gmask,
@@ -421,32 +429,51 @@ __global__ __launch_bounds__(1024) void k_conv3_sparse_dgrad(const float* __rest
     __syncthreads();
     const int rows_per_wave = (P + 15) / 16;
     const int row_lo = wave * rows_per_wave, row_hi = min(P, row_lo + rows_per_wave);
-    // first sorted position whose row is >= row_lo
-    int lo = 0, hi = C3;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (s_row[s_list[mid]] < row_lo) lo = mid + 1; else hi = mid;
-    }
-    int pos = lo;
-    while (pos < C3) {
-        const int row = s_row[s_list[pos]];
-        if (row >= row_hi) break;
-        float2 acc = make_float2(0.f, 0.f);
-        while (pos < C3) {
-            const int ch = s_list[pos];
-            if (s_row[ch] != row) break;
-            const float cf = s_coef[ch];
-            const float2 w = *(const float2*)(W3 + (size_t)ch * C2 + 2 * lane);
-            acc.x = fmaf(cf, w.x, acc.x);
-            acc.y = fmaf(cf, w.y, acc.y);
-            ++pos;
+    // this wave's piece of the sorted list: positions whose row lies in [row_lo, row_hi)
+    auto first_at_least = [&](int row) {
+        int lo = 0, hi = C3;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_row[s_list[mid]] < row) lo = mid + 1; else hi = mid;
         }
-        float2* out = (float2*)(dh + ((size_t)b * P + row) * C2 + 2 * lane);
-        float2 v = *out;
-        v.x += acc.x;
-        v.y += acc.y;
-        *out = v;
+        return lo;
+    };
+    const int begin = first_at_least(row_lo), end = row_lo < row_hi ? first_at_least(row_hi) : begin;
+    int cur = -1;
+    float2 acc = make_float2(0.f, 0.f);
+    // a row is flushed once, by the one wave that owns it: a single add per address, so the hardware float
+    // atomic is order-free here and spares the read half of a read-modify-write
+    auto flush = [&]() {
+        if (cur >= 0) {
+            float* out = dh + ((size_t)b * P + cur) * C2 + 2 * lane;
+            unsafeAtomicAdd(out, acc.x);
+            unsafeAtomicAdd(out + 1, acc.y);
+        }
+    };
+    for (int base = begin; base < end; base += 4) {
+        int row[4];
+        float cf[4];
+        float2 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                 // four weight rows in flight
+            const int p = base + u;
+            const int ch = s_list[p < end ? p : end - 1];
+            row[u] = s_row[ch];
+            cf[u] = p < end ? s_coef[ch] : 0.f;
+            w[u] = *(const float2*)(W3 + (size_t)ch * C2 + 2 * lane);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (base + u < end && row[u] != cur) {
+                flush();
+                cur = row[u];
+                acc = make_float2(0.f, 0.f);
+            }
+            acc.x = fmaf(cf[u], w[u].x, acc.x);
+            acc.y = fmaf(cf[u], w[u].y, acc.y);
+        }
     }
+    flush();
 }
 
 // dW[c,j] = A_c sum_b g[b,c] h[arg(b,c), j] + M (p_c abar_j + q_c sum_i W[c,i] Cov[i][j]); block per channel
@@ -497,7 +524,7 @@ hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const 
     if (e != hipSuccess) return e;
     const int chunks = t_gram_chunks(M);
     hipLaunchKernelGGL(gram_f64_kernel, dim3(3, chunks), dim3(256), 0, s, h2, M, GRAM_ROWS_PER_CHUNK, gram_part);
-    hipLaunchKernelGGL(k_gram_finalize, dim3(C2 * C2 / 256), dim3(256), 0, s, (const double*)gram_part, chunks,
+    hipLaunchKernelGGL(k_gram_finalize, dim3(C2 * C2 / 16), dim3(256), 0, s, (const double*)gram_part, chunks,
                        (const double*)w.abar_d, M, w.cov);
     hipLaunchKernelGGL(k_conv3_stats_pack, dim3(C3), dim3(128), 0, s, W3, b3, gamma, beta, (const double*)w.cov,
                        (const double*)w.abar_d, M, momentum, mean, rstd, running_mean, running_var, w.w3p, w.sh);

@@ -76,3 +76,26 @@ for n in osd:
         g = msd[n].cpu().numpy()
         r0 = sd[n].numpy()      # the update is 0.1 * batch statistic: error relative to that part
         print(f"{n:32s} max rel err of the batch statistic {np.max(np.abs(g - r) / (np.abs(r - 0.9 * r0) + 1e-9)):9.2e}")
+
+# the same step in float64: how far is each float32 implementation from it?
+o64 = po.build_cls(P, k, sd, eval_mode=False).double()
+out64, _ = o64(x.double())
+F.nll_loss(out64, target).backward()
+ref64 = {n: p.grad.numpy() for n, p in o64.named_parameters()}
+print("against the float64 step: torch float32 | HIP")
+for n, p in m.named_parameters():
+    r = ref64[n]
+    den = max(np.abs(r).max(), 1e-12)
+    print(f"{n:28s} {np.abs(ref[n] - r).max() / den:9.2e} | {np.abs(p.grad.cpu().numpy() - r).max() / den:9.2e}")
+with torch.no_grad():
+    o4 = po.build_cls(P, k, sd, eval_mode=False).double()
+    xd = x.double()
+    trans = o4.feat.stn(xd)
+    xt = torch.bmm(xd.transpose(2, 1), trans).transpose(2, 1)
+    h = torch.relu(o4.feat.bn1(o4.feat.conv1(xt)))
+    h = torch.relu(o4.feat.bn2(o4.feat.conv2(h)))
+    y = o4.feat.bn3(o4.feat.conv3(h))
+    top2 = y.topk(2, dim=2).values
+    gap = (top2[..., 0] - top2[..., 1]) / y.abs().amax(dim=2).clamp_min(1e-9)
+    print("trunk max-pool: (b,c) pairs whose two largest values are within 1e-6 / 1e-5 / 1e-4 relative:",
+          int((gap < 1e-6).sum()), int((gap < 1e-5).sum()), int((gap < 1e-4).sum()), "of", gap.numel())
