@@ -114,7 +114,6 @@ struct Conv3Ws {
     double* cov;       // [128,128] covariance of the input rows
     float* w3p;        // [1024*128] weights scaled by gamma*rstd, packed for the product/max kernel
     float* sh;         // [1024] shift added after the max
-    float* yh;         // [B,1024] normalised pre-activation at the arg-max row
     float* gmask;      // [B,1024] pooled gradient after the ReLU mask
     float* G;          // [128,128] W^T diag(q) W
     float* ub;         // [128] constant row of the dense input gradient
@@ -122,7 +121,8 @@ struct Conv3Ws {
 hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta, int B,
                        int P, int relu_out, float momentum, double* part, double* gram_part, const Conv3Ws& w, float* mean,
                        float* rstd, float* running_mean, float* running_var, float* pooled, int* arg, hipStream_t s);
-hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* dpooled,
+hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta,
+                       const float* dpooled,
                        const float* pooled, const int* arg, const float* mean, const float* rstd, int B, int P,
                        int relu_out, const Conv3Ws& w, float* m1, float* m2, float* dW3, float* dgamma, float* dbeta,
                        float* dh2, hipStream_t s);

@@ -67,7 +67,6 @@ struct TrainWs {
             s->c3.cov = a.take<double>((size_t)C2 * C2);
             s->c3.w3p = a.take<float>((size_t)C3 * C2);
             s->c3.sh = a.take<float>(C3);
-            s->c3.yh = a.take<float>((size_t)B * C3);
             s->c3.gmask = a.take<float>((size_t)B * C3);
             s->c3.G = a.take<float>((size_t)C2 * C2);
             s->c3.ub = a.take<float>(C2);
@@ -202,7 +201,7 @@ int bwd_stack(StackWs& S, const float* const* p, float* const* g, int u1, const 
     const int M = B * P;
     // conv3 / bn3 / max-pool
     HIP_TRY(pngpd::t_conv3_bwd(S.h2, cslot(p, u1 + 2, PNGPD_F_WEIGHT), cslot(p, u1 + 2, PNGPD_F_BIAS),
-                               cslot(p, u1 + 2, PNGPD_F_BN_WEIGHT), dpooled, S.pooled, S.arg, S.mean[2], S.rstd[2], B, P,
+                               cslot(p, u1 + 2, PNGPD_F_BN_WEIGHT), cslot(p, u1 + 2, PNGPD_F_BN_BIAS), dpooled, S.pooled, S.arg, S.mean[2], S.rstd[2], B, P,
                                relu_out, S.c3, W.m1, W.m2, slot(g, u1 + 2, PNGPD_F_WEIGHT),
                                slot(g, u1 + 2, PNGPD_F_BN_WEIGHT), slot(g, u1 + 2, PNGPD_F_BN_BIAS), S.dh2, s));
     HIP_TRY(pngpd::t_fill(slot(g, u1 + 2, PNGPD_F_BIAS), C3, 0.f, s));

@@ -314,50 +314,46 @@ __global__ __launch_bounds__(TC_THREADS, 2) void conv3_pool_train_kernel(const f
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-// One wave per (b, c): yhat at the arg-max row, recomputed as a 128-term product; also the masked pooled
-// gradient.  block = 4 waves x 16 consecutive channels each.
-__global__ __launch_bounds__(256) void k_conv3_arg_yhat(const float* __restrict__ h, const float* __restrict__ W3,
-                                                        const float* __restrict__ b3, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd,
-                                                        const float* __restrict__ dpooled,
-                                                        const float* __restrict__ pooled, const int* __restrict__ arg,
-                                                        int B, int P, int relu, float* __restrict__ yh,
-                                                        float* __restrict__ gmask) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t first = ((size_t)blockIdx.x * 4 + wave) * 16;
-    if (first >= (size_t)B * C3) return;
-    const int b = (int)(first / C3), c0 = (int)(first - (size_t)b * C3);
-#pragma unroll 4
-    for (int j = 0; j < 16; ++j) {
-        const int c = c0 + j;
-        const int row = arg[(size_t)b * C3 + c];
-        const float2 hv = *(const float2*)(h + ((size_t)b * P + row) * C2 + 2 * lane);
-        const float2 wv = *(const float2*)(W3 + (size_t)c * C2 + 2 * lane);
-        float d = fmaf(hv.x, wv.x, hv.y * wv.y);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off);
-        if (lane == 0) {
-            const size_t o = (size_t)b * C3 + c;
-            yh[o] = (d + b3[c] - mean[c]) * rstd[c];
-            float g = dpooled[o];
-            if (relu && !(pooled[o] > 0.f)) g = 0.f;
-            gmask[o] = g;
-        }
-    }
-}
-
-// m1 = sum_b g / M, m2 = sum_b g*yhat / M, dgamma = sum g*yhat, dbeta = sum g; 16 channels x 16 candidate lanes
-__global__ __launch_bounds__(256) void k_conv3_bwd_reduce(const float* __restrict__ gmask, const float* __restrict__ yh,
-                                                          int B, int P, float* __restrict__ m1, float* __restrict__ m2,
+// m1 = sum_b g / M, m2 = sum_b g*yhat / M, dgamma = sum g*yhat, dbeta = sum g, and the masked pooled gradient g.
+// yhat at the arg-max row follows from the pooled value itself: pooled (before the ReLU) = gamma*yhat + beta; where
+// the ReLU clipped it g is 0 and yhat is not needed.  Only a channel with gamma == 0 (or tiny against beta)
+// recomputes the 128-term product at its arg-max row.  block = 16 channels x 16 candidate lanes.
+__global__ __launch_bounds__(256) void k_conv3_bwd_reduce(const float* __restrict__ h, const float* __restrict__ W3,
+                                                          const float* __restrict__ b3,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd,
+                                                          const float* __restrict__ dpooled,
+                                                          const float* __restrict__ pooled, const int* __restrict__ arg,
+                                                          int B, int P, int relu, float* __restrict__ gmask,
+                                                          float* __restrict__ m1, float* __restrict__ m2,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ double shm[2][16][16];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
+    const float ga = gamma[c], be = beta[c];
+    // (pooled - beta) / gamma loses digits when |gamma| << |beta|: such channels take the product path as well
+    const bool direct = ga != 0.f && fabsf(ga) > 1e-2f * fabsf(be);
+    const float inv_ga = direct ? 1.f / ga : 0.f;
     double s1 = 0.0, s2 = 0.0;
     for (int b = rl; b < B; b += 16) {
-        const float g = gmask[(size_t)b * C3 + c];
+        const size_t o = (size_t)b * C3 + c;
+        const float pv = pooled[o];
+        float g = dpooled[o];
+        if (relu && !(pv > 0.f)) g = 0.f;
+        gmask[o] = g;
+        float yh;
+        if (direct) {
+            yh = (pv - be) * inv_ga;
+        } else {
+            const float* hr = h + ((size_t)b * P + arg[o]) * C2;
+            const float* wr = W3 + (size_t)c * C2;
+            float d = 0.f;
+            for (int k = 0; k < C2; ++k) d = fmaf(hr[k], wr[k], d);
+            yh = (d + b3[c] - mean[c]) * rstd[c];
+        }
         s1 += (double)g;
-        s2 += (double)(g * yh[(size_t)b * C3 + c]);
+        s2 += (double)(g * yh);
     }
     shm[0][rl][cl] = s1;
     shm[1][rl][cl] = s2;
@@ -403,77 +399,103 @@ __global__ __launch_bounds__(128) void k_conv3_bwd_G(const float* __restrict__ W
 }
 
 // Rows that hold a maximum: dh[b*P + arg(b,c), :] += A_c g[b,c] W[c,:].  One workgroup of 16 waves per
-// candidate: the 1024 channels are sorted by (arg row, channel) with a rank count, wave w owns the rows
-// [w*ceil(P/16), ...) - a contiguous piece of the sorted list - and adds up each of its rows in channel
-// order before it is added to the row once (fixed order).
+// candidate: the 1024 channels are sorted by (arg row, channel) and every wave adds up a 64-entry piece of the
+// sorted list, run by run, in a fixed order.
 __global__ __launch_bounds__(1024) void k_conv3_sparse_dgrad(const float* __restrict__ W3, const float* __restrict__ gamma,
                                                              const float* __restrict__ rstd,
                                                              const float* __restrict__ gmask,
                                                              const int* __restrict__ arg, int P,
                                                              float* __restrict__ dh) {
-    __shared__ int s_row[C3];
+    __shared__ int s_key[C3];
     __shared__ float s_coef[C3];
-    __shared__ short s_list[C3];
     const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
-    const int my = arg[(size_t)b * C3 + c];
-    s_row[c] = my;
+    // keys (row << 10 | channel) sorted ascending by a bitonic network: order by row, then by channel
+    s_key[c] = (arg[(size_t)b * C3 + c] << 10) | c;
     s_coef[c] = gamma[c] * rstd[c] * gmask[(size_t)b * C3 + c];
     __syncthreads();
-    int rank = 0;
-#pragma unroll 8
-    for (int o = 0; o < C3; ++o) {
-        const int a = s_row[o];
-        rank += (a < my || (a == my && o < c)) ? 1 : 0;
-    }
-    s_list[rank] = (short)c;
-    __syncthreads();
-    const int rows_per_wave = (P + 15) / 16;
-    const int row_lo = wave * rows_per_wave, row_hi = min(P, row_lo + rows_per_wave);
-    // this wave's piece of the sorted list: positions whose row lies in [row_lo, row_hi)
-    auto first_at_least = [&](int row) {
-        int lo = 0, hi = C3;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_row[s_list[mid]] < row) lo = mid + 1; else hi = mid;
+    for (int k = 2; k <= C3; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int other = c ^ j;
+            if (other > c) {
+                const int x = s_key[c], y = s_key[other];
+                if ((x > y) == ((c & k) == 0)) {
+                    s_key[c] = y;
+                    s_key[other] = x;
+                }
+            }
+            __syncthreads();
         }
-        return lo;
-    };
-    const int begin = first_at_least(row_lo), end = row_lo < row_hi ? first_at_least(row_hi) : begin;
-    int cur = -1;
+    // Wave w walks positions [64w, 64w+64) of the sorted list and adds up runs of equal rows.  A run that lies
+    // inside the wave's piece is added to its row of dh directly - one add per address, so the hardware float
+    // atomic is order-free there and spares the read half of a read-modify-write.  The first and the last run of
+    // a piece may continue in a neighbouring piece: they go to an LDS edge list that wave 0 combines in order.
+    __shared__ float s_edge[32][C2];
+    __shared__ int s_edge_row[32];
+    float* dhb = dh + (size_t)b * P * C2 + 2 * lane;
+    const int begin = wave * 64, end = begin + 64;
+    int cur = -1, runs = 0;
     float2 acc = make_float2(0.f, 0.f);
-    // a row is flushed once, by the one wave that owns it: a single add per address, so the hardware float
-    // atomic is order-free here and spares the read half of a read-modify-write
-    auto flush = [&]() {
-        if (cur >= 0) {
-            float* out = dh + ((size_t)b * P + cur) * C2 + 2 * lane;
-            unsafeAtomicAdd(out, acc.x);
-            unsafeAtomicAdd(out + 1, acc.y);
+    auto close_run = [&](bool last) {
+        if (cur < 0) return;
+        if (runs == 1 || last) {
+            const int e = 2 * wave + (runs == 1 ? 0 : 1);
+            s_edge[e][2 * lane] = acc.x;
+            s_edge[e][2 * lane + 1] = acc.y;
+            if (lane == 0) s_edge_row[e] = cur;
+        } else {
+            unsafeAtomicAdd(dhb + (size_t)cur * C2, acc.x);
+            unsafeAtomicAdd(dhb + (size_t)cur * C2 + 1, acc.y);
         }
     };
-    for (int base = begin; base < end; base += 4) {
-        int row[4];
-        float cf[4];
-        float2 w[4];
+    if (lane == 0) s_edge_row[2 * wave + 1] = -1;     // stays empty when the piece is a single run
+    constexpr int DEPTH = 8;                          // weight rows in flight
+    for (int base = begin; base < end; base += DEPTH) {
+        int row[DEPTH];
+        float cf[DEPTH];
+        float2 w[DEPTH];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                 // four weight rows in flight
-            const int p = base + u;
-            const int ch = s_list[p < end ? p : end - 1];
-            row[u] = s_row[ch];
-            cf[u] = p < end ? s_coef[ch] : 0.f;
+        for (int u = 0; u < DEPTH; ++u) {
+            const int key = s_key[base + u];
+            const int ch = key & (C3 - 1);
+            row[u] = key >> 10;
+            cf[u] = s_coef[ch];
             w[u] = *(const float2*)(W3 + (size_t)ch * C2 + 2 * lane);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (base + u < end && row[u] != cur) {
-                flush();
+        for (int u = 0; u < DEPTH; ++u) {
+            if (row[u] != cur) {
+                close_run(false);
                 cur = row[u];
+                ++runs;
                 acc = make_float2(0.f, 0.f);
             }
             acc.x = fmaf(cf[u], w[u].x, acc.x);
             acc.y = fmaf(cf[u], w[u].y, acc.y);
         }
     }
-    flush();
+    close_run(true);
+    __syncthreads();
+    if (wave != 0) return;
+    cur = -1;
+    acc = make_float2(0.f, 0.f);
+    for (int e = 0; e < 32; ++e) {
+        const int r = s_edge_row[e];
+        if (r < 0) continue;
+        if (r != cur) {
+            if (cur >= 0) {
+                unsafeAtomicAdd(dhb + (size_t)cur * C2, acc.x);
+                unsafeAtomicAdd(dhb + (size_t)cur * C2 + 1, acc.y);
+            }
+            cur = r;
+            acc = make_float2(0.f, 0.f);
+        }
+        acc.x += s_edge[e][2 * lane];
+        acc.y += s_edge[e][2 * lane + 1];
+    }
+    if (cur >= 0) {
+        unsafeAtomicAdd(dhb + (size_t)cur * C2, acc.x);
+        unsafeAtomicAdd(dhb + (size_t)cur * C2 + 1, acc.y);
+    }
 }
 
 // dW[c,j] = A_c sum_b g[b,c] h[arg(b,c), j] + M (p_c abar_j + q_c sum_i W[c,i] Cov[i][j]); block per channel
@@ -545,15 +567,14 @@ hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const 
     return hipGetLastError();
 }
 
-hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* dpooled,
+hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta,
+                       const float* dpooled,
                        const float* pooled, const int* arg, const float* mean, const float* rstd, int B, int P,
                        int relu_out, const Conv3Ws& w, float* m1, float* m2, float* dW3, float* dgamma, float* dbeta,
                        float* dh2, hipStream_t s) {
     const int M = B * P;
-    hipLaunchKernelGGL(k_conv3_arg_yhat, dim3((unsigned)(((size_t)B * C3 + 63) / 64)), dim3(256), 0, s, h2, W3, b3, mean,
-                       rstd, dpooled, pooled, arg, B, P, relu_out, w.yh, w.gmask);
-    hipLaunchKernelGGL(k_conv3_bwd_reduce, dim3(C3 / 16), dim3(256), 0, s, (const float*)w.gmask, (const float*)w.yh, B,
-                       P, m1, m2, dgamma, dbeta);
+    hipLaunchKernelGGL(k_conv3_bwd_reduce, dim3(C3 / 16), dim3(256), 0, s, h2, W3, b3, gamma, beta, mean, rstd, dpooled,
+                       pooled, arg, B, P, relu_out, w.gmask, m1, m2, dgamma, dbeta);
     hipLaunchKernelGGL(k_conv3_bwd_G, dim3(C2 + 1), dim3(128), 0, s, W3, b3, gamma, mean, rstd, (const float*)m1,
                        (const float*)m2, w.G, w.ub);
     hipError_t e = launch_fc_f32(h2, w.G, w.ub, dh2, M, C2, C2, 0, s);     // G is symmetric: h G = h G^T

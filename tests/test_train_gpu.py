@@ -230,3 +230,37 @@ def test_gradients_and_statistics_at_odd_shapes(P, B, k, seed):
     for n in ref_sd:
         if n.endswith(("running_mean", "running_var")):
             np.testing.assert_allclose(got_sd[n].cpu().numpy(), ref_sd[n].numpy(), rtol=2e-4, atol=2e-5, err_msg=n)
+
+
+def test_zero_and_tiny_batchnorm_scale_on_the_pooled_layers():
+    """gamma == 0 makes every point of a candidate tie (the first one wins, as in torch) and leaves only dgamma
+    non-zero for that channel; a gamma that is tiny against beta must not lose the normalised value either."""
+    P, k, seed, B, gain = 200, 2, 31, 7, 1.3
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
+    target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) * k).astype(np.int64))
+    sd = synth.torch_state_dict(seed, k, 1.0, gain)
+    for name in ("feat.bn3.weight", "feat.stn.bn3.weight"):
+        w = sd[name].clone()
+        w[::7] = 0.0
+        w[3::7] = 1e-4 * torch.sign(w[3::7])
+        sd[name] = w
+    oracle = po.build_cls(P, k, sd, eval_mode=False)
+    out, _ = oracle(x)
+    F.nll_loss(out, target).backward()
+    m = PointNetCls(P, 3, k)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    out2, _ = m(x.cuda())
+    F.nll_loss(out2, target.cuda()).backward()
+    np.testing.assert_allclose(out2.detach().cpu().numpy(), out.detach().numpy(), atol=1e-4)
+    ref = {n: p.grad.numpy() for n, p in oracle.named_parameters()}
+    for n, p in m.named_parameters():
+        g = p.grad.cpu().numpy()
+        if np.abs(ref[n]).max() < 1e-5:
+            assert np.abs(g).max() < 1e-5, n
+        else:
+            assert rel_err(g, ref[n]) < 2e-3, (n, rel_err(g, ref[n]))
+    for name in ("feat.bn3.weight", "feat.stn.bn3.weight"):       # the channels in question, one by one
+        g, r = m.get_parameter(name).grad.cpu().numpy(), ref[name]
+        scale = np.abs(r).max()
+        assert np.abs(g[::7] - r[::7]).max() < 2e-3 * scale and np.abs(g[3::7] - r[3::7]).max() < 2e-3 * scale, name
