@@ -551,6 +551,7 @@ hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const 
     hipLaunchKernelGGL(k_conv3_stats_pack, dim3(C3), dim3(128), 0, s, W3, b3, gamma, beta, (const double*)w.cov,
                        (const double*)w.abar_d, M, momentum, mean, rstd, running_mean, running_var, w.w3p, w.sh);
     // enough workgroups for two per CU: split the channels of a candidate when the batch is small
+    // (B = 256 on 256 CUs: 444 / 408 / 422 / 458 us with 1 / 2 / 4 / 8 pieces)
     int dev = 0, n_cu = 0;
     e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
