@@ -11,6 +11,9 @@ main_test.py:48-56), so its checkpoints are pickles that name the classes `model
     PointNet contains and nn.DataParallel (unwrapped).  Nothing else in the file can be instantiated;
   * plain `state_dict` files (with or without the `module.` prefix of DataParallel).
 
+Files in torch's pre-1.6 non-zip container are refused with an explanation (load_checkpoint.__doc__);
+`save_checkpoint` writes whole-module pickles under the reference's class path that both sides can read.
+
 The shipped checkpoints of the reference are not available to this build, so this is verified on
 pickles of the same structure made by the tests, not on the originals.
 """
@@ -59,29 +62,75 @@ def _from_state_dict(sd, num_points):
     return model
 
 
-def load_checkpoint(path, num_points=None, device="cuda"):
-    """Returns a pointnetgpd_amd.pointnet.PointNetCls in eval mode on `device`.
+class _LegacyPath:
+    """While active, `model.pointnet.{STN3d,PointNetfeat,PointNetCls}` resolve to subclasses of this package's
+    modules - for nothing but one load or save."""
 
-    num_points is only needed for state_dict files (a whole-module pickle carries it)."""
-    legacy = _legacy_classes()
-    allowed = list(legacy.values()) + [nn.Conv1d, nn.BatchNorm1d, nn.Linear, nn.MaxPool1d, nn.ReLU, nn.DataParallel,
-                                       nn.Dropout, collections.OrderedDict, torch.device]
-    # the legacy names must also resolve as `sys.modules['model.pointnet'].X` for nothing but the load
-    saved = {k: sys.modules.get(k) for k in ("model", _LEGACY_MODULE)}
-    pkg, mod = types.ModuleType("model"), types.ModuleType(_LEGACY_MODULE)
-    for name, cls in legacy.items():
-        setattr(mod, name, cls)
-    pkg.pointnet = mod
-    sys.modules["model"], sys.modules[_LEGACY_MODULE] = pkg, mod
-    try:
-        with torch.serialization.safe_globals(allowed):
-            obj = torch.load(path, map_location="cpu", weights_only=True)
-    finally:
-        for k, v in saved.items():
+    def __enter__(self):
+        self.classes = _legacy_classes()
+        self._saved = {k: sys.modules.get(k) for k in ("model", _LEGACY_MODULE)}
+        pkg, mod = types.ModuleType("model"), types.ModuleType(_LEGACY_MODULE)
+        for name, cls in self.classes.items():
+            setattr(mod, name, cls)
+        pkg.pointnet = mod
+        sys.modules["model"], sys.modules[_LEGACY_MODULE] = pkg, mod
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self._saved.items():
             if v is None:
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+        return False
+
+
+def save_checkpoint(model, path, old_container=False):
+    """Whole-module pickle (`torch.save(model, path)`, main_1v.py:350) under the reference's class path
+    `model.pointnet.PointNetCls`: the file loads with `load_checkpoint` and, since the attribute layout is the
+    reference's, with the reference's own `torch.load` (main_1v.py:201, main_test.py:56).
+
+    old_container=True writes torch's pre-1.6 non-zip container, which is what the reference asks for
+    (`_use_new_zipfile_serialization=False`); `load_checkpoint` cannot read that one back (see there), the
+    reference can."""
+    natives = [(m, type(m)) for m in model.modules() if type(m) in (_pn.STN3d, _pn.PointNetfeat, _pn.PointNetCls)]
+    with _LegacyPath() as lp:
+        try:
+            for m, cls in natives:
+                m.__class__ = lp.classes[cls.__name__]
+            torch.save(model, path, _use_new_zipfile_serialization=not old_container)
+        finally:
+            for m, cls in natives:
+                m.__class__ = cls
+
+
+def load_checkpoint(path, num_points=None, device="cuda"):
+    """Returns a pointnetgpd_amd.pointnet.PointNetCls in eval mode on `device`.
+
+    num_points is only needed for state_dict files (a whole-module pickle carries it).
+
+    State_dict files load from either container.  Whole-module pickles in torch's pre-1.6 NON-zip container (`_use_new_zipfile_serialization=False`, which
+    main_1v.py:350 asks for) are refused: that container records module classes through pickle persistent ids,
+    which torch's restricted unpickler rejects, and this loader does not fall back to unrestricted unpickling.
+    Re-save such a file where it was made (`torch.save(model.state_dict(), path)` or a plain `torch.save(model,
+    path)`), or point `load_checkpoint` at the state_dict."""
+    import pickle
+    import zipfile
+    with _LegacyPath() as lp:
+        allowed = list(lp.classes.values()) + [_pn.STN3d, _pn.PointNetfeat, _pn.PointNetCls, nn.Conv1d, nn.BatchNorm1d,
+                                               nn.Linear, nn.MaxPool1d, nn.ReLU, nn.DataParallel, nn.Dropout,
+                                               collections.OrderedDict, torch.device]
+        try:
+            with torch.serialization.safe_globals(allowed):
+                obj = torch.load(path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError as e:
+            if not zipfile.is_zipfile(path) and "persistent_load" in str(e):
+                raise ValueError(
+                    f"{path} holds a whole module in torch's pre-1.6 non-zip container; it can only be read by "
+                    "unrestricted unpickling, which this loader does not do. Re-save it with "
+                    "torch.save(model.state_dict(), ...) or torch.save(model, ...) in the environment that wrote "
+                    "it.") from None
+            raise
     if isinstance(obj, nn.DataParallel):
         obj = obj.module
     if isinstance(obj, dict):

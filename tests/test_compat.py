@@ -85,3 +85,40 @@ def test_loaded_legacy_checkpoint_scores_like_the_restatement(legacy_pickle):
         want, _ = ref.eval()(x)
     got, _ = m(x.cuda())
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4)
+
+
+def test_save_checkpoint_round_trip_and_class_path(tmp_path):
+    """Whole-module pickles written here carry the reference's class path (so the reference's torch.load resolves
+    them to ITS classes) and read back bit-exactly; the model object is left untouched."""
+    m = pn.PointNetCls(64, 3, 3)
+    m.load_state_dict(synth.torch_state_dict(4, 3, 1.0))
+    path = str(tmp_path / "saved.model")
+    compat.save_checkpoint(m, path)
+    assert type(m) is pn.PointNetCls and type(m.feat.stn) is pn.STN3d
+    assert "model" not in sys.modules and "model.pointnet" not in sys.modules
+    import zipfile
+    with zipfile.ZipFile(path) as z:
+        pkl = z.read([n for n in z.namelist() if n.endswith("data.pkl")][0])
+    assert b"model.pointnet" in pkl and b"pointnetgpd_amd" not in pkl
+    back = compat.load_checkpoint(path, device="cpu")
+    assert type(back) is pn.PointNetCls and back.num_points == 64 and back.fc3.out_features == 3
+    for (k, a), (_, b) in zip(m.state_dict().items(), back.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_old_container_is_refused_with_an_explanation(tmp_path):
+    """main_1v.py:350 writes torch's pre-1.6 non-zip container; torch's restricted unpickler cannot read whole
+    modules from it and the loader does not fall back to unrestricted unpickling."""
+    import warnings
+    m = pn.PointNetCls(32, 3, 2)
+    path = str(tmp_path / "old.model")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        compat.save_checkpoint(m, path, old_container=True)
+    with pytest.raises(ValueError, match="non-zip container"):
+        compat.load_checkpoint(path, device="cpu")
+    # a state_dict in the old container holds tensors only and loads
+    sd_path = str(tmp_path / "old_sd.pth")
+    torch.save(m.state_dict(), sd_path, _use_new_zipfile_serialization=False)
+    back = compat.load_checkpoint(sd_path, num_points=32, device="cpu")
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), back.state_dict().values()))
