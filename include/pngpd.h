@@ -238,6 +238,13 @@ int pngpd_train_forward(int B, int P, int k, const float* x_dev, float* const* p
                         int n_slots, float momentum, float* logp_dev, float* trans_dev,
                         float* feat_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* The point index that holds each channel's maximum in the two MaxPool1d(num_points) of the last
+ * pngpd_train_forward on this workspace (model/pointnet.py:33 in the STN, :147 in the trunk; the first
+ * maximum, as max_pool1d reports it): int32 [B,1024] each, either pointer may be NULL.  These are the
+ * rows the backward pass routes the pooled gradient to. */
+int pngpd_train_argmax(int B, int P, int k, const void* workspace_dev, size_t workspace_bytes,
+                       int* stn_arg_dev, int* trunk_arg_dev, void* stream);
+
 /* dlogp_dev [B,k]: gradient of the loss w.r.t. the log-probabilities; dtrans_dev [B,3,3] optional
  * gradient w.r.t. the returned transform (the reference discards it, main_1v.py:268). */
 int pngpd_train_backward(int B, int P, int k, const float* x_dev, const float* const* params_dev,

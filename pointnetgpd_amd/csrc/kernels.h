@@ -96,6 +96,8 @@ int t_red_blocks(int M);                     // row blocks of the column reducti
 int t_tn_chunks(int M);                      // partials of a weight-gradient product
 constexpr int GRAM_ROWS_PER_CHUNK = 1024;    // rows of one Gram-matrix partial (multiple of 32)
 inline int t_gram_chunks(int M) { return (M + GRAM_ROWS_PER_CHUNK - 1) / GRAM_ROWS_PER_CHUNK; }
+// doubles of the Gram workspace: per chunk a 128x128 partial matrix and 128 column sums
+inline size_t t_gram_ws_doubles(int M) { return (size_t)t_gram_chunks(M) * (C2 * C2 + C2); }
 
 hipError_t t_points_to_rows(const float* x, const float* trans, float* X3, int B, int P, hipStream_t s);
 hipError_t t_conv1_fwd(const float* X3, const float* W1, const float* b1, float* y1, int M, hipStream_t s);
@@ -106,7 +108,6 @@ hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, co
 hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean, const float* rstd,
                     const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
                     float* dbeta, hipStream_t s);
-hipError_t t_col_mean(const float* A, int M, int C, double* part, double* abar_d, hipStream_t s);
 
 // conv3 + BatchNorm (batch statistics) + max over points without the [M,1024] activation (train_conv3.hip)
 struct Conv3Ws {
@@ -119,7 +120,7 @@ struct Conv3Ws {
     float* ub;         // [128] constant row of the dense input gradient
 };
 hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta, int B,
-                       int P, int relu_out, float momentum, double* part, double* gram_part, const Conv3Ws& w, float* mean,
+                       int P, int relu_out, float momentum, double* gram_part, const Conv3Ws& w, float* mean,
                        float* rstd, float* running_mean, float* running_var, float* pooled, int* arg, hipStream_t s);
 hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta,
                        const float* dpooled,

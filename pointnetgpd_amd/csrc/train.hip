@@ -131,9 +131,9 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ A, 
     }
 }
 
-// The finalize kernels sum nblk partials per column.  Block = 16 columns x 16 row lanes: every row
-// lane sums every 16th partial, the 16 lane sums are then added in a fixed order (reproducible).
-constexpr int FIN_COLS = 16, FIN_LANES = 16;
+// The finalize kernels sum nblk partials per column.  Block = 4 columns x 64 row lanes: every row
+// lane sums every 64th partial, the 64 lane sums are then added in a fixed order (reproducible).
+constexpr int FIN_COLS = 4, FIN_LANES = 64;
 
 __device__ __forceinline__ void sum_partials2(const double* __restrict__ part, int nblk, int C, int c, int rl,
                                               double& s1, double& s2) {
@@ -141,6 +141,7 @@ __device__ __forceinline__ void sum_partials2(const double* __restrict__ part, i
     const int cl = threadIdx.x & (FIN_COLS - 1);
     double a = 0.0, b = 0.0;
     if (c < C)
+#pragma unroll 4
         for (int i = rl; i < nblk; i += FIN_LANES) {
             a += part[((size_t)i * 2 + 0) * C + c];
             b += part[((size_t)i * 2 + 1) * C + c];
@@ -218,17 +219,6 @@ __global__ void k_bn_bwd_dense(float* __restrict__ dh, const float* __restrict__
     if (h != nullptr && !(h[i] > 0.f)) g = 0.f;
     const float yh = (y[i] - mean[c]) * rstd[c];
     dh[i] = gamma[c] * rstd[c] * (g - m1[c] - yh * m2[c]);
-}
-
-// Column means of A[M,C] from the mode-0 partials, in double.
-__global__ __launch_bounds__(256) void k_colmean_finalize(const double* __restrict__ part, int nblk,
-                                                          const float* __restrict__ A, int M, int C,
-                                                          double* __restrict__ abar_d) {
-    const int c = blockIdx.x * FIN_COLS + (threadIdx.x & (FIN_COLS - 1)), rl = threadIdx.x / FIN_COLS;
-    double s1, s2;
-    sum_partials2(part, nblk, C, c, rl, s1, s2);
-    if (rl != 0 || c >= C) return;
-    abar_d[c] = (double)A[c] + s1 / M;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -570,14 +560,6 @@ hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean
     hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta);
     hipLaunchKernelGGL(k_bn_bwd_dense, grid1((size_t)M * C), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, m1, m2,
                        (size_t)M * C, C);
-    return hipGetLastError();
-}
-hipError_t t_col_mean(const float* A, int M, int C, double* part, double* abar_d, hipStream_t s) {
-    const int nblk = t_red_blocks(M);
-    hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, A, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, 0, part);
-    hipLaunchKernelGGL(k_colmean_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, (const double*)part, nblk, A, M, C,
-                       abar_d);
     return hipGetLastError();
 }
 hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s) {

@@ -87,7 +87,7 @@ struct TrainWs {
         const size_t nblk = (size_t)pngpd::t_red_blocks((int)M);
         part = a.take<double>(nblk * 2 * C3);
         const size_t chunks = (size_t)pngpd::t_tn_chunks((int)M);
-        gram_part = a.take<double>((size_t)pngpd::t_gram_chunks((int)M) * C2 * C2);
+        gram_part = a.take<double>(pngpd::t_gram_ws_doubles((int)M));
         size_t tn = chunks * (size_t)C2 * C1;       // conv2 weight-gradient partials
         if (tn < (size_t)512 * 1024) tn = (size_t)512 * 1024;
         tn_part = a.take<float>(tn);
@@ -149,7 +149,7 @@ int fwd_stack(StackWs& S, float* const* p, int u1, const float* x, const float* 
     }
     const int u3 = u1 + 2;
     HIP_TRY(pngpd::t_conv3_fwd(S.h2, slot(p, u3, PNGPD_F_WEIGHT), slot(p, u3, PNGPD_F_BIAS), slot(p, u3, PNGPD_F_BN_WEIGHT),
-                               slot(p, u3, PNGPD_F_BN_BIAS), B, P, relu_out, momentum, part, gram_part, S.c3, S.mean[2],
+                               slot(p, u3, PNGPD_F_BN_BIAS), B, P, relu_out, momentum, gram_part, S.c3, S.mean[2],
                                S.rstd[2], slot(p, u3, PNGPD_F_BN_MEAN), slot(p, u3, PNGPD_F_BN_VAR), S.pooled, S.arg, s));
     return PNGPD_OK;
 }
@@ -254,6 +254,18 @@ int pngpd_train_forward(int B, int P, int k, const float* x_dev, float* const* p
         return rc;
     if (feat_dev)
         HIP_TRY(hipMemcpyAsync(feat_dev, W.trunk.pooled, (size_t)B * C3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return PNGPD_OK;
+}
+
+int pngpd_train_argmax(int B, int P, int k, const void* workspace_dev, size_t workspace_bytes, int* stn_arg_dev,
+                       int* trunk_arg_dev, void* stream) {
+    int rc = check_shape(B, P, k, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    TrainWs W((void*)workspace_dev, B, P, k);
+    const size_t bytes = (size_t)B * C3 * sizeof(int);
+    hipStream_t s = (hipStream_t)stream;
+    if (stn_arg_dev) HIP_TRY(hipMemcpyAsync(stn_arg_dev, W.stn.arg, bytes, hipMemcpyDeviceToDevice, s));
+    if (trunk_arg_dev) HIP_TRY(hipMemcpyAsync(trunk_arg_dev, W.trunk.arg, bytes, hipMemcpyDeviceToDevice, s));
     return PNGPD_OK;
 }
 

@@ -37,10 +37,12 @@ constexpr float BN_EPS3 = 1e-5f;
 typedef __attribute__((ext_vector_type(4))) double f64x4;
 constexpr int GR_LD = 80;       // LDS row stride in floats: the 4 k rows one instruction reads fall on distinct banks
 
+// The diagonal blocks also add up the columns they load: colsum[chunk][128].
 __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__ A, int M, int rows_per_chunk,
-                                                       double* __restrict__ part) {
+                                                       double* __restrict__ part, double* __restrict__ colsum) {
     __shared__ __attribute__((aligned(16))) float sI[32 * GR_LD];
     __shared__ __attribute__((aligned(16))) float sJ[32 * GR_LD];
+    __shared__ double s_cs[16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, kq = lane >> 4, wi = wave >> 1, wj = wave & 1;
     const int i0 = blockIdx.x == 2 ? 64 : 0, j0 = blockIdx.x == 0 ? 0 : 64;
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
     float4 va[2], vb[2];
+    double cs[4] = {0.0, 0.0, 0.0, 0.0};
     auto load_tile = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -69,6 +72,10 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__
         for (int i = 0; i < 2; ++i) {
             *(float4*)(sI + (lrow + 16 * i) * GR_LD + lcol) = va[i];
             *(float4*)(sJ + (lrow + 16 * i) * GR_LD + lcol) = vb[i];
+            cs[0] += (double)va[i].x;
+            cs[1] += (double)va[i].y;
+            cs[2] += (double)va[i].z;
+            cs[3] += (double)va[i].w;
         }
         __syncthreads();
         if (mb + 32 < row_end) load_tile(mb + 32);
@@ -94,6 +101,31 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__
                 const int i = i0 + wi * 32 + 16 * a + kq + 4 * r, j = j0 + wj * 32 + 16 * b + c;
                 out[(size_t)i * C2 + j] = acc[a][b][r];
             }
+    if (i0 != j0) return;                      // column sums: once per column, from the diagonal blocks
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_cs[lrow][lcol + e] = cs[e];
+    __syncthreads();
+    if (tid < 64) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += s_cs[k][tid];
+        colsum[(size_t)blockIdx.y * C2 + i0 + tid] = t;
+    }
+}
+
+// abar[i] = sum_chunks colsum[chunk][i] / M; block = 16 columns x 16 chunk lanes
+__global__ __launch_bounds__(256) void k_gram_mean(const double* __restrict__ colsum, int chunks, int M,
+                                                   double* __restrict__ abar_d) {
+    __shared__ double sh[16][16];
+    const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + el;
+    double s = 0.0;
+    for (int c = rl; c < chunks; c += 16) s += colsum[(size_t)c * C2 + i];
+    sh[rl][el] = s;
+    __syncthreads();
+    if (rl != 0) return;
+    s = 0.0;
+    for (int k = 0; k < 16; ++k) s += sh[k][el];
+    abar_d[i] = s / M;
 }
 
 // cov[i][j] = sum_chunks S_chunk[i][j] / M - abar_i abar_j.  block = 16 elements x 16 chunk lanes: a lane sums every
@@ -539,13 +571,14 @@ __global__ __launch_bounds__(128) void k_conv3_wgrad(const float* __restrict__ h
 // launch helpers
 // ---------------------------------------------------------------------------------------------
 hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta, int B,
-                       int P, int relu_out, float momentum, double* part, double* gram_part, const Conv3Ws& w, float* mean,
-                       float* rstd, float* running_mean, float* running_var, float* pooled, int* arg, hipStream_t s) {
+                       int P, int relu_out, float momentum, double* gram_part, const Conv3Ws& w, float* mean, float* rstd,
+                       float* running_mean, float* running_var, float* pooled, int* arg, hipStream_t s) {
     const int M = B * P;
-    hipError_t e = t_col_mean(h2, M, C2, part, w.abar_d, s);
-    if (e != hipSuccess) return e;
+    hipError_t e;
     const int chunks = t_gram_chunks(M);
-    hipLaunchKernelGGL(gram_f64_kernel, dim3(3, chunks), dim3(256), 0, s, h2, M, GRAM_ROWS_PER_CHUNK, gram_part);
+    double* colsum = gram_part + (size_t)chunks * C2 * C2;
+    hipLaunchKernelGGL(gram_f64_kernel, dim3(3, chunks), dim3(256), 0, s, h2, M, GRAM_ROWS_PER_CHUNK, gram_part, colsum);
+    hipLaunchKernelGGL(k_gram_mean, dim3(C2 / 16), dim3(256), 0, s, (const double*)colsum, chunks, M, w.abar_d);
     hipLaunchKernelGGL(k_gram_finalize, dim3(C2 * C2 / 16), dim3(256), 0, s, (const double*)gram_part, chunks,
                        (const double*)w.abar_d, M, w.cov);
     hipLaunchKernelGGL(k_conv3_stats_pack, dim3(C3), dim3(128), 0, s, W3, b3, gamma, beta, (const double*)w.cov,

@@ -87,6 +87,19 @@ def train_forward(model, x, ws=None):
     return logp, trans, ws, x
 
 
+def critical_points(ws, B, P, k=2):
+    """(stn_arg, trunk_arg), int32 [B,1024] each: the point that holds every channel's maximum in the two
+    max-pools (model/pointnet.py:33, :147) of the last train-mode forward that used workspace `ws`."""
+    lib = _lib.load()
+    stn = torch.empty((B, 1024), dtype=torch.int32, device=ws.device)
+    trunk = torch.empty_like(stn)
+    with torch.cuda.device(ws.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(ws.device).cuda_stream)
+        _lib.check(lib.pngpd_train_argmax(B, P, k, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                          ctypes.c_void_p(stn.data_ptr()), ctypes.c_void_p(trunk.data_ptr()), stream))
+    return stn, trunk
+
+
 def train_backward(model, x, logp, dlogp, dtrans, ws, grad_of):
     """Backward of train_forward.  grad_of(param) -> tensor that receives that parameter's gradient."""
     lib = _lib.load()

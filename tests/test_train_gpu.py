@@ -201,12 +201,13 @@ def test_every_gradient_against_oracle():
             np.testing.assert_allclose(got_sd[n].cpu().numpy(), ref_sd[n].numpy(), rtol=2e-4, atol=2e-5, err_msg=n)
 
 
-@pytest.mark.parametrize("P,B,k,seed", [(5, 16, 2, 5), (40, 8, 3, 6), (257, 9, 2, 7), (64, 70, 2, 8)])
+@pytest.mark.parametrize("P,B,k,seed", [(5, 16, 2, 5), (40, 8, 3, 6), (257, 9, 2, 7)])
 def test_gradients_and_statistics_at_odd_shapes(P, B, k, seed):
     """Shapes that leave point tiles, channel splits and per-wave row ranges of the conv3 path partly empty.
-    (The max over points makes the gradient discontinuous where two points tie to within float32 rounding: two
-    correct float32 implementations may then pick different rows.  The seeded cases here have no such near-tie;
-    tools/debug_train.py compares both implementations with a float64 step and counts the near-ties.)"""
+    (The max over points and the ReLUs make the gradient discontinuous: where two points tie, or a pre-activation
+    sits at zero, to within float32 rounding, two correct float32 implementations differ in isolated elements.
+    These small seeded cases stay clear of that; larger ones are covered by the tie-proof test below, and
+    tools/debug_train.py compares both implementations with a float64 step.)"""
     gain = 1.3
     x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
     target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) * k).astype(np.int64))
@@ -264,3 +265,72 @@ def test_zero_and_tiny_batchnorm_scale_on_the_pooled_layers():
         g, r = m.get_parameter(name).grad.cpu().numpy(), ref[name]
         scale = np.abs(r).max()
         assert np.abs(g[::7] - r[::7]).max() < 2e-3 * scale and np.abs(g[3::7] - r[3::7]).max() < 2e-3 * scale, name
+
+
+def forced_pool_forward(o, x, arg_stn, arg_trunk):
+    """Train-mode forward of the restated network (float64) whose two max-pools read the GIVEN point of every
+    (candidate, channel) instead of searching the maximum; returns (logp, pooled values and true maxima)."""
+    def stack(mod, h, relu_out, arg):
+        h = torch.relu(mod.bn1(mod.conv1(h)))
+        h = torch.relu(mod.bn2(mod.conv2(h)))
+        y = mod.bn3(mod.conv3(h))
+        if relu_out:
+            y = torch.relu(y)
+        return y.gather(2, arg.long().unsqueeze(2)).squeeze(2), y.max(dim=2).values
+
+    stn = o.feat.stn
+    ps, ms = stack(stn, x, True, arg_stn)
+    h = torch.relu(stn.bn4(stn.fc1(ps)))
+    h = torch.relu(stn.bn5(stn.fc2(h)))
+    iden = torch.eye(3, dtype=x.dtype).reshape(1, 9)
+    trans = (stn.fc3(h) + iden).reshape(-1, 3, 3)
+    xt = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
+    pt, mt = stack(o.feat, xt, False, arg_trunk)
+    h = torch.relu(o.bn1(o.fc1(pt)))
+    h = torch.relu(o.bn2(o.fc2(h)))
+    return F.log_softmax(o.fc3(h), dim=1), (ps, ms), (pt, mt)
+
+
+@pytest.mark.parametrize("P,B,k,seed", [(130, 70, 2, 8), (64, 70, 2, 13), (37, 150, 2, 9), (300, 20, 3, 10)])
+def test_gradients_with_the_arg_max_rows_the_kernel_chose(P, B, k, seed):
+    """The max over points makes the gradient discontinuous where two points of a candidate tie to within float32
+    rounding, so two correct implementations may route a channel's gradient to different rows.  This test takes
+    the rows the HIP forward chose, checks that each holds the maximum (to rounding), and compares every gradient
+    with a float64 step of the restated network that is forced onto the same rows: tie-proof, at any shape.
+    What remains are the ReLU kinks: with ~10^6 pre-activations per case a few lie within float32 rounding of zero,
+    and where such a point is also an arg-max row (which concentrates gradient) a mask that falls the other way
+    changes one bias-gradient element by ~1e-2 and everything upstream of it by ~1e-3.  The seeded cases below are
+    ones where float32 and float64 agree on every mask (seed 8 at P=64, B=70 is one where they do not: trunk bn2,
+    candidate 55, channel 48, point 32 sits at -7.8e-7; tools/diag/kink.py shows the error in exactly that
+    channel)."""
+    from pointnetgpd_amd import training
+    gain = 1.3
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
+    target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) * k).astype(np.int64))
+    sd = synth.torch_state_dict(seed, k, 1.0, gain)
+    m = hip_train_model(P, k, seed, gain)
+    logp, trans, ws, xc = training.train_forward(m, x.cuda())
+    loss, dlogp = nll_loss(logp, target.cuda())
+    grads = {id(p): torch.zeros_like(p) for p in m.parameters()}
+    training.train_backward(m, xc, logp, dlogp, None, ws, lambda p: grads[id(p)])
+    arg_stn, arg_trunk = (a.cpu() for a in training.critical_points(ws, B, P, k))
+    assert int(arg_stn.min()) >= 0 and int(arg_stn.max()) < P and int(arg_trunk.min()) >= 0 and int(arg_trunk.max()) < P
+
+    o = po.build_cls(P, k, sd, eval_mode=False).double()
+    ref_logp, (ps, ms), (pt, mt) = forced_pool_forward(o, x.double(), arg_stn, arg_trunk)
+    for chosen, true_max in ((ps, ms), (pt, mt)):          # the chosen row holds the maximum
+        scale = float(true_max.abs().max())
+        assert float((true_max - chosen).max()) < 2e-5 * scale
+    assert (logp.cpu().double() - ref_logp).abs().max().item() < 5e-5
+    F.nll_loss(ref_logp, target).backward()
+    assert abs(loss.item() - F.nll_loss(ref_logp, target).item()) < 2e-5
+    bad = []
+    for n, p in m.named_parameters():
+        r = o.get_parameter(n).grad.numpy()
+        g = grads[id(p)].cpu().numpy()
+        if np.abs(r).max() < 1e-7:
+            if np.abs(g).max() >= 1e-5:
+                bad.append((n, float(np.abs(g).max())))
+        elif rel_err(g, r) >= 2e-4:
+            bad.append((n, float(rel_err(g, r))))
+    assert not bad, bad
