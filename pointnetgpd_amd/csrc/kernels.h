@@ -94,8 +94,14 @@ constexpr int TN_ROWS_PER_CHUNK = 2048;      // rows of one weight-gradient part
 
 int t_red_blocks(int M);                     // row blocks of the column reductions
 int t_tn_chunks(int M);                      // partials of a weight-gradient product
-constexpr int GRAM_ROWS_PER_CHUNK = 1024;    // rows of one Gram-matrix partial (multiple of 32)
-inline int t_gram_chunks(int M) { return (M + GRAM_ROWS_PER_CHUNK - 1) / GRAM_ROWS_PER_CHUNK; }
+// Gram-matrix partials: about 256 chunks of rows (3 workgroups each: a whole number per CU on a 256-CU part),
+// at least 256 and a multiple of 32 rows per chunk
+inline int t_gram_rows_per_chunk(int M) {
+    int rows = (M + 255) / 256;
+    if (rows < 256) rows = 256;
+    return (rows + 31) & ~31;
+}
+inline int t_gram_chunks(int M) { return (M + t_gram_rows_per_chunk(M) - 1) / t_gram_rows_per_chunk(M); }
 // doubles of the Gram workspace: per chunk a 128x128 partial matrix and 128 column sums
 inline size_t t_gram_ws_doubles(int M) { return (size_t)t_gram_chunks(M) * (C2 * C2 + C2); }
 

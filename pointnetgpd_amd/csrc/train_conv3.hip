@@ -31,7 +31,7 @@ constexpr float BN_EPS3 = 1e-5f;
 // forward: statistics from the Gram matrix, scaled + packed weights
 // ---------------------------------------------------------------------------------------------
 // Gram matrix S = h^T h of the [M,128] input rows on the f64 MFMA (products of floats are exact in double,
-// the sums run in double): partial sums over chunks of GRAM_ROWS_PER_CHUNK rows.
+// the sums run in double): partial sums over chunks of t_gram_rows_per_chunk(M) rows.
 // grid (3, chunks): 64x64 output blocks (0,0), (0,1), (1,1) - block (1,0) is the transpose of (0,1).
 // v_mfma_f64_16x16x4_f64 lane l: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D reg r = [row (l>>4) + 4r][col l&15].
 typedef __attribute__((ext_vector_type(4))) double f64x4;
@@ -577,7 +577,7 @@ hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const 
     hipError_t e;
     const int chunks = t_gram_chunks(M);
     double* colsum = gram_part + (size_t)chunks * C2 * C2;
-    hipLaunchKernelGGL(gram_f64_kernel, dim3(3, chunks), dim3(256), 0, s, h2, M, GRAM_ROWS_PER_CHUNK, gram_part, colsum);
+    hipLaunchKernelGGL(gram_f64_kernel, dim3(3, chunks), dim3(256), 0, s, h2, M, t_gram_rows_per_chunk(M), gram_part, colsum);
     hipLaunchKernelGGL(k_gram_mean, dim3(C2 / 16), dim3(256), 0, s, (const double*)colsum, chunks, M, w.abar_d);
     hipLaunchKernelGGL(k_gram_finalize, dim3(C2 * C2 / 16), dim3(256), 0, s, (const double*)gram_part, chunks,
                        (const double*)w.abar_d, M, w.cov);
