@@ -90,7 +90,7 @@ hipError_t launch_voxel_unique(const float* pts, int S, int n, void* ws, float* 
                                hipStream_t s);
 
 // ---- training step (train.hip) ---------------------------------------------------------------
-constexpr int TN_ROWS_PER_CHUNK = 2048;      // rows of one weight-gradient partial (multiple of 32)
+constexpr int TN_ROWS_PER_CHUNK = 512;       // rows of one weight-gradient partial (multiple of 32)
 
 int t_red_blocks(int M);                     // row blocks of the column reductions
 int t_tn_chunks(int M);                      // partials of a weight-gradient product

@@ -321,12 +321,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     }
 }
 
-// out[i] = sum over chunks of part[chunk][i]  (fixed order: reproducible)
-__global__ void k_reduce_chunks(const float* __restrict__ part, int chunks, size_t n, float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum over chunks of part[chunk][i].  block = 16 elements x 16 chunk lanes: a lane sums every 16th
+// chunk, the lane sums are added in a fixed order (reproducible).
+__global__ __launch_bounds__(256) void k_reduce_chunks(const float* __restrict__ part, int chunks, size_t n,
+                                                       float* __restrict__ out) {
+    __shared__ float sh[16][16];
+    const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + el;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * n + i];
+    if (i < n)
+#pragma unroll 4
+        for (int c = rl; c < chunks; c += 16) s += part[(size_t)c * n + i];
+    sh[rl][el] = s;
+    __syncthreads();
+    if (rl != 0 || i >= n) return;
+    s = 0.f;
+    for (int k = 0; k < 16; ++k) s += sh[k][el];
     out[i] = s;
 }
 
@@ -572,10 +582,12 @@ int t_tn_chunks(int M) { return (M + TN_ROWS_PER_CHUNK - 1) / TN_ROWS_PER_CHUNK;
 hipError_t t_gemm_tn(const float* dY, const float* Hm, float* part, float* dW, int M, int N, int K, hipStream_t s) {
     if (N % 64 != 0 || K % 64 != 0) return hipErrorInvalidValue;
     const int chunks = t_tn_chunks(M);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(K / 64, N / 64, chunks), dim3(256), 0, s, dY, Hm, part, M, N, K,
-                       TN_ROWS_PER_CHUNK);
-    hipLaunchKernelGGL(k_reduce_chunks, grid1((size_t)N * K), dim3(256), 0, s, (const float*)part, chunks,
-                       (size_t)N * K, dW);
+    // a single chunk is the result itself
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(K / 64, N / 64, chunks), dim3(256), 0, s, dY, Hm, chunks == 1 ? dW : part, M,
+                       N, K, TN_ROWS_PER_CHUNK);
+    if (chunks > 1)
+        hipLaunchKernelGGL(k_reduce_chunks, grid1((size_t)N * K, 16), dim3(256), 0, s, (const float*)part, chunks,
+                           (size_t)N * K, dW);
     return hipGetLastError();
 }
 hipError_t t_conv1_bwd(const float* dy1, const float* X3, const float* W1, int M, double* part, float* dW1,
