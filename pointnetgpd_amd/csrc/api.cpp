@@ -34,12 +34,22 @@ using pngpd::fail;
 
 struct DevBuf {
     void* p = nullptr;
+    size_t bytes = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t upload(const void* src, size_t bytes, hipStream_t s) {
-        if (p) { (void)hipFree(p); p = nullptr; }
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) return e;
-        return hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, s);
+    // a re-upload of the same size (weights after a training step) keeps the allocation: no hipFree, which
+    // would wait for the whole device, and the copy is ordered on the stream behind earlier forwards
+    hipError_t upload(const void* src, size_t n, hipStream_t s) {
+        if (p && n != bytes) {
+            (void)hipFree(p);
+            p = nullptr;
+            bytes = 0;
+        }
+        if (!p) {
+            hipError_t e = hipMalloc(&p, n);
+            if (e != hipSuccess) return e;
+            bytes = n;
+        }
+        return hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, s);
     }
 };
 
@@ -304,7 +314,13 @@ int pngpd_forward_infer_timed(const pngpd_model* m, const float* x_dev, int layo
     if (!conv_ms_out) return fail(PNGPD_ERR_INVALID, "pngpd_forward_infer_timed: NULL conv_ms_out");
     if (m && !(m->parts & PNGPD_PART_TRUNK)) return fail(PNGPD_ERR_STATE, "pngpd_forward_infer_timed: model has no trunk");
     hipEvent_t ev[4];
-    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&ev[i]));
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipEventCreate(&ev[i]);
+        if (e != hipSuccess) {
+            while (i-- > 0) (void)hipEventDestroy(ev[i]);
+            return fail(PNGPD_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+        }
+    }
     int rc = forward_impl(m, x_dev, layout, B, P, precision, logp_dev, trans_dev, feat_dev, workspace_dev,
                           workspace_bytes, stream, ev);
     if (rc == PNGPD_OK) {
