@@ -245,6 +245,20 @@ int pngpd_train_forward(int B, int P, int k, const float* x_dev, float* const* p
 int pngpd_train_argmax(int B, int P, int k, const void* workspace_dev, size_t workspace_bytes,
                        int* stn_arg_dev, int* trunk_arg_dev, void* stream);
 
+/* Read-only view of an activation that the last pngpd_train_forward saved in this workspace for the backward
+ * pass (row-major float32; per-point layers as [B*P, C] rows ordered (candidate, point)):
+ *   *_H1 [B*P,64], *_H2 [B*P,128]  relu(bn(conv)) of the first two layers (model/pointnet.py:30-31, :143-145)
+ *   *_POOLED [B,1024]              output of the max-pool (:33-34, :147)
+ *   *_A1 [B,512], *_A2 [B,256]     relu(bn(fc)) of the regressor / classifier (:36-37, :187-188)
+ * Their signs are the ReLU masks the backward pass applies. */
+enum {
+    PNGPD_SAVED_STN_H1 = 0, PNGPD_SAVED_STN_H2 = 1, PNGPD_SAVED_STN_POOLED = 2, PNGPD_SAVED_STN_A1 = 3,
+    PNGPD_SAVED_STN_A2 = 4, PNGPD_SAVED_TRUNK_H1 = 5, PNGPD_SAVED_TRUNK_H2 = 6, PNGPD_SAVED_TRUNK_POOLED = 7,
+    PNGPD_SAVED_HEAD_A1 = 8, PNGPD_SAVED_HEAD_A2 = 9
+};
+int pngpd_train_saved(int B, int P, int k, const void* workspace_dev, size_t workspace_bytes, int which,
+                      const float** data_dev_out, size_t* count_out);
+
 /* dlogp_dev [B,k]: gradient of the loss w.r.t. the log-probabilities; dtrans_dev [B,3,3] optional
  * gradient w.r.t. the returned transform (the reference discards it, main_1v.py:268). */
 int pngpd_train_backward(int B, int P, int k, const float* x_dev, const float* const* params_dev,

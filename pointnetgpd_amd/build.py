@@ -29,6 +29,7 @@ LIB_SOURCES = [
     "voxel.hip",
     "train.hip",
     "train_conv3.hip",
+    "tall_gemm.hip",
     "train_api.cpp",
 ]
 

@@ -89,6 +89,18 @@ size_t voxel_workspace_bytes(int n);
 hipError_t launch_voxel_unique(const float* pts, int S, int n, void* ws, float* out, long long capacity, int* count,
                                hipStream_t s);
 
+// ---- tall-matrix products (tall_gemm.hip) ------------------------------------------------------
+constexpr int TALL_GEMM_MAX_BLOCKS = 512;    // persistent workgroups: two per CU on a 256-CU part
+bool tall_gemm_supports(int M, int N, int K);          // K, N in {64, 128}
+int tall_gemm_blocks(int M);                           // workgroups launched = statistic records written
+// Y[M,N] = act(X[M,K] B + bias); B[k][n] = W[k*N+n] (w_is_kn) or W[n*K+k]; bias optional.
+// stat_rec (optional): [tall_gemm_blocks(M)][N][3] doubles (count, mean, sum of squared deviations) of the columns of
+// X B + bias, for t_stats_from_records.
+hipError_t launch_tall_gemm(const float* X, const float* W, int w_is_kn, const float* bias, float* Y, int M, int N,
+                            int K, int relu, double* stat_rec, hipStream_t s);
+hipError_t t_stats_from_records(const double* rec, int nrec, int M, int C, float momentum, float* mean, float* rstd,
+                                float* running_mean, float* running_var, hipStream_t s);
+
 // ---- training step (train.hip) ---------------------------------------------------------------
 constexpr int TN_ROWS_PER_CHUNK = 512;       // rows of one weight-gradient partial (multiple of 32)
 
@@ -113,7 +125,7 @@ hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, co
                         float* h, int M, int C, int relu, hipStream_t s);
 hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean, const float* rstd,
                     const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
-                    float* dbeta, hipStream_t s);
+                    float* dbeta, float* dbias_zero, hipStream_t s);
 
 // conv3 + BatchNorm (batch statistics) + max over points without the [M,1024] activation (train_conv3.hip)
 struct Conv3Ws {
@@ -131,8 +143,8 @@ hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const 
 hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta,
                        const float* dpooled,
                        const float* pooled, const int* arg, const float* mean, const float* rstd, int B, int P,
-                       int relu_out, const Conv3Ws& w, float* m1, float* m2, float* dW3, float* dgamma, float* dbeta,
-                       float* dh2, hipStream_t s);
+                       int relu_out, const Conv3Ws& w, float* m1, float* m2, float* dW3, float* db3_zero, float* dgamma,
+                       float* dbeta, float* dh2, hipStream_t s);
 hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s);
 hipError_t t_gemm_tn(const float* dY, const float* Hm, float* part, float* dW, int M, int N, int K, hipStream_t s);
 hipError_t t_conv1_bwd(const float* dy1, const float* X3, const float* W1, int M, double* part, float* dW1,
@@ -141,7 +153,6 @@ hipError_t t_trans_grad(const float* x, const float* dX3, int B, int P, const fl
                         hipStream_t s);
 hipError_t t_small_bwd(const float* dZ, const float* A, const float* W, float* dA, float* dW, float* db, int M, int N,
                        int K, hipStream_t s);
-hipError_t t_fill(float* p, size_t n, float v, hipStream_t s);
 hipError_t t_logsoftmax_bwd(const float* logp, const float* dlogp, float* dlogits, int B, int k, hipStream_t s);
 hipError_t t_nll_loss(const float* logp, const long long* target, int B, int k, float* loss, float* dlogp,
                       hipStream_t s);

@@ -181,10 +181,11 @@ __global__ __launch_bounds__(256) void k_stats_finalize(const double* __restrict
     }
 }
 
-// m1 = s1/M, m2 = s2/M; dgamma = s2, dbeta = s1
+// m1 = s1/M, m2 = s2/M; dgamma = s2, dbeta = s1; the bias of the layer in front of the BatchNorm gets its exact 0
 __global__ __launch_bounds__(256) void k_bnbwd_finalize(const double* __restrict__ part, int nblk, int M, int C,
                                                         float* __restrict__ m1, float* __restrict__ m2,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        float* __restrict__ dbias_zero) {
     const int c = blockIdx.x * FIN_COLS + (threadIdx.x & (FIN_COLS - 1)), rl = threadIdx.x / FIN_COLS;
     double s1, s2;
     sum_partials2(part, nblk, C, c, rl, s1, s2);
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256) void k_bnbwd_finalize(const double* __restrict
     m2[c] = (float)(s2 / M);
     dgamma[c] = (float)s2;
     dbeta[c] = (float)s1;
+    if (dbias_zero != nullptr) dbias_zero[c] = 0.f;
 }
 
 // h = relu((y - mean)*rstd*gamma + beta)   (relu optional)
@@ -478,13 +480,6 @@ __global__ __launch_bounds__(256) void k_small_wgrad(const float* __restrict__ d
     }
 }
 
-// db[n] = sum_m dY[m,n] for layers WITHOUT a following BatchNorm is handled by k_small_wgrad;
-// zero-fill for layers that feed a BatchNorm.
-__global__ void k_fill(float* __restrict__ p, size_t n, float v) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 // grad of log_softmax: dlogits = dlogp - softmax * sum_j dlogp_j  (logp are log-probabilities)
 __global__ void k_logsoftmax_bwd(const float* __restrict__ logp, const float* __restrict__ dlogp,
                                  float* __restrict__ dlogits, int B, int k) {
@@ -563,11 +558,12 @@ hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, co
 // dh (in place) <- dy ; also dgamma, dbeta
 hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean, const float* rstd,
                     const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
-                    float* dbeta, hipStream_t s) {
+                    float* dbeta, float* dbias_zero, hipStream_t s) {
     const int nblk = t_red_blocks(M);
     hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, (const float*)dh, h, y, mean, rstd, M,
                        C, 1, part);
-    hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta);
+    hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta,
+                       dbias_zero);
     hipLaunchKernelGGL(k_bn_bwd_dense, grid1((size_t)M * C), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, m1, m2,
                        (size_t)M * C, C);
     return hipGetLastError();
@@ -607,11 +603,6 @@ hipError_t t_small_bwd(const float* dZ, const float* A, const float* W, float* d
                        int K, hipStream_t s) {
     hipLaunchKernelGGL(k_small_dgrad, grid1((size_t)M * K), dim3(256), 0, s, dZ, W, dA, M, N, K);
     hipLaunchKernelGGL(k_small_wgrad, dim3((K + 15) / 16, N), dim3(256), 0, s, dZ, A, dW, db, M, N, K);
-    return hipGetLastError();
-}
-hipError_t t_fill(float* p, size_t n, float v, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_fill, grid1(n), dim3(256), 0, s, p, n, v);
     return hipGetLastError();
 }
 hipError_t t_logsoftmax_bwd(const float* logp, const float* dlogp, float* dlogits, int B, int k, hipStream_t s) {

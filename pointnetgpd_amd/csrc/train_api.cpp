@@ -139,11 +139,16 @@ int fwd_stack(StackWs& S, float* const* p, int u1, const float* x, const float* 
     HIP_TRY(pngpd::t_conv1_fwd(S.X3, slot(p, u1, PNGPD_F_WEIGHT), slot(p, u1, PNGPD_F_BIAS), S.y1, M, s));
     for (int l = 0; l < 2; ++l) {
         const int u = u1 + l;
-        if (l > 0)
-            HIP_TRY(pngpd::launch_fc_f32(hs[l - 1], slot(p, u, PNGPD_F_WEIGHT), slot(p, u, PNGPD_F_BIAS), ys[l], M,
-                                         ch[l], ch[l - 1], 0, s));
-        HIP_TRY(pngpd::t_bn_stats(ys[l], M, ch[l], momentum, part, S.mean[l], S.rstd[l], slot(p, u, PNGPD_F_BN_MEAN),
-                                  slot(p, u, PNGPD_F_BN_VAR), s));
+        if (l > 0) {
+            // conv2 with the column statistics of its output taken from the accumulators
+            HIP_TRY(pngpd::launch_tall_gemm(hs[l - 1], slot(p, u, PNGPD_F_WEIGHT), 0, slot(p, u, PNGPD_F_BIAS), ys[l], M,
+                                            ch[l], ch[l - 1], 0, part, s));
+            HIP_TRY(pngpd::t_stats_from_records(part, pngpd::tall_gemm_blocks(M), M, ch[l], momentum, S.mean[l],
+                                                S.rstd[l], slot(p, u, PNGPD_F_BN_MEAN), slot(p, u, PNGPD_F_BN_VAR), s));
+        } else {
+            HIP_TRY(pngpd::t_bn_stats(ys[l], M, ch[l], momentum, part, S.mean[l], S.rstd[l],
+                                      slot(p, u, PNGPD_F_BN_MEAN), slot(p, u, PNGPD_F_BN_VAR), s));
+        }
         HIP_TRY(pngpd::t_bn_act_fwd(ys[l], S.mean[l], S.rstd[l], slot(p, u, PNGPD_F_BN_WEIGHT),
                                     slot(p, u, PNGPD_F_BN_BIAS), hs[l], M, ch[l], 1, s));
     }
@@ -183,15 +188,15 @@ int bwd_fc(FcWs& F, const float* const* p, float* const* g, int u1, const float*
                                slot(g, u1 + 2, PNGPD_F_BIAS), B, n_last, 256, s));
     // layer 2
     HIP_TRY(pngpd::t_bn_bwd(F.da2, F.a2, F.z2, F.mean[1], F.rstd[1], cslot(p, u1 + 1, PNGPD_F_BN_WEIGHT), B, 256,
-                            W.part, W.m1, W.m2, slot(g, u1 + 1, PNGPD_F_BN_WEIGHT), slot(g, u1 + 1, PNGPD_F_BN_BIAS), s));
+                            W.part, W.m1, W.m2, slot(g, u1 + 1, PNGPD_F_BN_WEIGHT), slot(g, u1 + 1, PNGPD_F_BN_BIAS),
+                            slot(g, u1 + 1, PNGPD_F_BIAS), s));
     HIP_TRY(pngpd::t_gemm_tn(F.da2, F.a1, W.tn_part, slot(g, u1 + 1, PNGPD_F_WEIGHT), B, 256, 512, s));
-    HIP_TRY(pngpd::t_fill(slot(g, u1 + 1, PNGPD_F_BIAS), 256, 0.f, s));
     HIP_TRY(pngpd::t_gemm_nn(F.da2, cslot(p, u1 + 1, PNGPD_F_WEIGHT), F.da1, B, 256, 512, s));
     // layer 1
     HIP_TRY(pngpd::t_bn_bwd(F.da1, F.a1, F.z1, F.mean[0], F.rstd[0], cslot(p, u1, PNGPD_F_BN_WEIGHT), B, 512, W.part,
-                            W.m1, W.m2, slot(g, u1, PNGPD_F_BN_WEIGHT), slot(g, u1, PNGPD_F_BN_BIAS), s));
+                            W.m1, W.m2, slot(g, u1, PNGPD_F_BN_WEIGHT), slot(g, u1, PNGPD_F_BN_BIAS),
+                            slot(g, u1, PNGPD_F_BIAS), s));
     HIP_TRY(pngpd::t_gemm_tn(F.da1, in, W.tn_part, slot(g, u1, PNGPD_F_WEIGHT), B, 512, 1024, s));
-    HIP_TRY(pngpd::t_fill(slot(g, u1, PNGPD_F_BIAS), 512, 0.f, s));
     HIP_TRY(pngpd::t_gemm_nn(F.da1, cslot(p, u1, PNGPD_F_WEIGHT), F.din, B, 512, 1024, s));
     return PNGPD_OK;
 }
@@ -202,21 +207,20 @@ int bwd_stack(StackWs& S, const float* const* p, float* const* g, int u1, const 
     // conv3 / bn3 / max-pool
     HIP_TRY(pngpd::t_conv3_bwd(S.h2, cslot(p, u1 + 2, PNGPD_F_WEIGHT), cslot(p, u1 + 2, PNGPD_F_BIAS),
                                cslot(p, u1 + 2, PNGPD_F_BN_WEIGHT), cslot(p, u1 + 2, PNGPD_F_BN_BIAS), dpooled, S.pooled, S.arg, S.mean[2], S.rstd[2], B, P,
-                               relu_out, S.c3, W.m1, W.m2, slot(g, u1 + 2, PNGPD_F_WEIGHT),
+                               relu_out, S.c3, W.m1, W.m2, slot(g, u1 + 2, PNGPD_F_WEIGHT), slot(g, u1 + 2, PNGPD_F_BIAS),
                                slot(g, u1 + 2, PNGPD_F_BN_WEIGHT), slot(g, u1 + 2, PNGPD_F_BN_BIAS), S.dh2, s));
-    HIP_TRY(pngpd::t_fill(slot(g, u1 + 2, PNGPD_F_BIAS), C3, 0.f, s));
     // conv2 / bn2
     HIP_TRY(pngpd::t_bn_bwd(S.dh2, S.h2, S.y2, S.mean[1], S.rstd[1], cslot(p, u1 + 1, PNGPD_F_BN_WEIGHT), M, C2, W.part,
-                            W.m1, W.m2, slot(g, u1 + 1, PNGPD_F_BN_WEIGHT), slot(g, u1 + 1, PNGPD_F_BN_BIAS), s));
+                            W.m1, W.m2, slot(g, u1 + 1, PNGPD_F_BN_WEIGHT), slot(g, u1 + 1, PNGPD_F_BN_BIAS),
+                            slot(g, u1 + 1, PNGPD_F_BIAS), s));
     HIP_TRY(pngpd::t_gemm_tn(S.dh2, S.h1, W.tn_part, slot(g, u1 + 1, PNGPD_F_WEIGHT), M, C2, C1, s));
-    HIP_TRY(pngpd::t_fill(slot(g, u1 + 1, PNGPD_F_BIAS), C2, 0.f, s));
-    HIP_TRY(pngpd::t_gemm_nn(S.dh2, cslot(p, u1 + 1, PNGPD_F_WEIGHT), S.dh1, M, C2, C1, s));
+    HIP_TRY(pngpd::launch_tall_gemm(S.dh2, cslot(p, u1 + 1, PNGPD_F_WEIGHT), 1, nullptr, S.dh1, M, C1, C2, 0, nullptr, s));
     // conv1 / bn1
     HIP_TRY(pngpd::t_bn_bwd(S.dh1, S.h1, S.y1, S.mean[0], S.rstd[0], cslot(p, u1, PNGPD_F_BN_WEIGHT), M, C1, W.part,
-                            W.m1, W.m2, slot(g, u1, PNGPD_F_BN_WEIGHT), slot(g, u1, PNGPD_F_BN_BIAS), s));
+                            W.m1, W.m2, slot(g, u1, PNGPD_F_BN_WEIGHT), slot(g, u1, PNGPD_F_BN_BIAS),
+                            slot(g, u1, PNGPD_F_BIAS), s));
     HIP_TRY(pngpd::t_conv1_bwd(S.dh1, S.X3, cslot(p, u1, PNGPD_F_WEIGHT), M, W.part, slot(g, u1, PNGPD_F_WEIGHT),
                                need_dX3 ? S.dX3 : nullptr, s));
-    HIP_TRY(pngpd::t_fill(slot(g, u1, PNGPD_F_BIAS), C1, 0.f, s));
     return PNGPD_OK;
 }
 
@@ -266,6 +270,29 @@ int pngpd_train_argmax(int B, int P, int k, const void* workspace_dev, size_t wo
     hipStream_t s = (hipStream_t)stream;
     if (stn_arg_dev) HIP_TRY(hipMemcpyAsync(stn_arg_dev, W.stn.arg, bytes, hipMemcpyDeviceToDevice, s));
     if (trunk_arg_dev) HIP_TRY(hipMemcpyAsync(trunk_arg_dev, W.trunk.arg, bytes, hipMemcpyDeviceToDevice, s));
+    return PNGPD_OK;
+}
+
+int pngpd_train_saved(int B, int P, int k, const void* workspace_dev, size_t workspace_bytes, int which,
+                      const float** data_dev_out, size_t* count_out) {
+    if (!data_dev_out || !count_out) return fail(PNGPD_ERR_INVALID, "pngpd_train_saved: NULL output");
+    int rc = check_shape(B, P, k, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    TrainWs W((void*)workspace_dev, B, P, k);
+    const size_t M = (size_t)B * P;
+    switch (which) {
+        case PNGPD_SAVED_STN_H1: *data_dev_out = W.stn.h1; *count_out = M * C1; break;
+        case PNGPD_SAVED_STN_H2: *data_dev_out = W.stn.h2; *count_out = M * C2; break;
+        case PNGPD_SAVED_STN_POOLED: *data_dev_out = W.stn.pooled; *count_out = (size_t)B * C3; break;
+        case PNGPD_SAVED_STN_A1: *data_dev_out = W.stn_fc.a1; *count_out = (size_t)B * 512; break;
+        case PNGPD_SAVED_STN_A2: *data_dev_out = W.stn_fc.a2; *count_out = (size_t)B * 256; break;
+        case PNGPD_SAVED_TRUNK_H1: *data_dev_out = W.trunk.h1; *count_out = M * C1; break;
+        case PNGPD_SAVED_TRUNK_H2: *data_dev_out = W.trunk.h2; *count_out = M * C2; break;
+        case PNGPD_SAVED_TRUNK_POOLED: *data_dev_out = W.trunk.pooled; *count_out = (size_t)B * C3; break;
+        case PNGPD_SAVED_HEAD_A1: *data_dev_out = W.head_fc.a1; *count_out = (size_t)B * 512; break;
+        case PNGPD_SAVED_HEAD_A2: *data_dev_out = W.head_fc.a2; *count_out = (size_t)B * 256; break;
+        default: return fail(PNGPD_ERR_INVALID, "pngpd_train_saved: unknown activation %d", which);
+    }
     return PNGPD_OK;
 }
 

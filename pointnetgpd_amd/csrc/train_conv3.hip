@@ -359,7 +359,8 @@ __global__ __launch_bounds__(256) void k_conv3_bwd_reduce(const float* __restric
                                                           const float* __restrict__ pooled, const int* __restrict__ arg,
                                                           int B, int P, int relu, float* __restrict__ gmask,
                                                           float* __restrict__ m1, float* __restrict__ m2,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ dbias_zero) {
     __shared__ double shm[2][16][16];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -402,6 +403,7 @@ __global__ __launch_bounds__(256) void k_conv3_bwd_reduce(const float* __restric
     m2[c] = (float)(s2 / M);
     dgamma[c] = (float)s2;
     dbeta[c] = (float)s1;
+    if (dbias_zero != nullptr) dbias_zero[c] = 0.f;      // the conv bias in front of the BatchNorm: exactly 0
 }
 
 // G[i][k] = sum_c q_c W[c,i] W[c,k] (blocks 0..127 = i), ub[k] = sum_c (p_c - q_c (mean_c - b_c)) W[c,k] (block 128)
@@ -604,14 +606,14 @@ hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const 
 hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta,
                        const float* dpooled,
                        const float* pooled, const int* arg, const float* mean, const float* rstd, int B, int P,
-                       int relu_out, const Conv3Ws& w, float* m1, float* m2, float* dW3, float* dgamma, float* dbeta,
-                       float* dh2, hipStream_t s) {
+                       int relu_out, const Conv3Ws& w, float* m1, float* m2, float* dW3, float* db3_zero, float* dgamma,
+                       float* dbeta, float* dh2, hipStream_t s) {
     const int M = B * P;
     hipLaunchKernelGGL(k_conv3_bwd_reduce, dim3(C3 / 16), dim3(256), 0, s, h2, W3, b3, gamma, beta, mean, rstd, dpooled,
-                       pooled, arg, B, P, relu_out, w.gmask, m1, m2, dgamma, dbeta);
+                       pooled, arg, B, P, relu_out, w.gmask, m1, m2, dgamma, dbeta, db3_zero);
     hipLaunchKernelGGL(k_conv3_bwd_G, dim3(C2 + 1), dim3(128), 0, s, W3, b3, gamma, mean, rstd, (const float*)m1,
                        (const float*)m2, w.G, w.ub);
-    hipError_t e = launch_fc_f32(h2, w.G, w.ub, dh2, M, C2, C2, 0, s);     // G is symmetric: h G = h G^T
+    hipError_t e = launch_tall_gemm(h2, w.G, 1, w.ub, dh2, M, C2, C2, 0, nullptr, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_conv3_sparse_dgrad, dim3(B), dim3(1024), 0, s, W3, gamma, rstd, (const float*)w.gmask, arg, P,
                        dh2);

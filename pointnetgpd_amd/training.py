@@ -100,6 +100,23 @@ def critical_points(ws, B, P, k=2):
     return stn, trunk
 
 
+SAVED = ("stn_h1", "stn_h2", "stn_pooled", "stn_a1", "stn_a2", "trunk_h1", "trunk_h2", "trunk_pooled", "head_a1",
+         "head_a2")
+
+
+def saved_activation(ws, B, P, k, name):
+    """View (no copy) of an activation the last train-mode forward saved in workspace `ws` for the backward pass:
+    one of SAVED; per-point layers come as [B*P, C] rows ordered (candidate, point)."""
+    lib = _lib.load()
+    ptr, count = ctypes.c_void_p(), ctypes.c_size_t()
+    _lib.check(lib.pngpd_train_saved(B, P, k, ctypes.c_void_p(ws.data_ptr()), ws.numel(), SAVED.index(name),
+                                     ctypes.byref(ptr), ctypes.byref(count)))
+    off = ptr.value - ws.data_ptr()
+    flat = ws[off:off + 4 * count.value].view(torch.float32)
+    rows = B if ("pooled" in name or "_a" in name) else B * P
+    return flat.view(rows, count.value // rows)
+
+
 def train_backward(model, x, logp, dlogp, dtrans, ws, grad_of):
     """Backward of train_forward.  grad_of(param) -> tensor that receives that parameter's gradient."""
     lib = _lib.load()

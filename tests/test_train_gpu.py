@@ -122,7 +122,9 @@ def test_fused_trainer_matches_autograd_path_and_oracle():
         got_sd = m.state_dict()
         for n in ("fc3.weight", "fc3.bias", "feat.stn.fc3.weight", "fc1.weight", "feat.conv3.weight",
                   "feat.stn.conv3.weight", "feat.conv2.weight", "feat.bn3.weight"):
-            clear = grads[n].abs() > 1e-5                      # skip |g| ~ 0: the update is a sign of noise
+            # skip |g| ~ 0: there the update lr*g/(|g| + eps) is a sign of noise, and just above it the eps term
+            # still turns a 1e-5 absolute gradient difference into a 1e-5 parameter difference
+            clear = grads[n].abs() > 1e-4
             diff = (got_sd[n].cpu() - ref_sd[n]).abs()[clear]
             assert float(diff.max()) < atol, (n, float(diff.max()))
         for n in ref_sd:
@@ -267,42 +269,52 @@ def test_zero_and_tiny_batchnorm_scale_on_the_pooled_layers():
         assert np.abs(g[::7] - r[::7]).max() < 2e-3 * scale and np.abs(g[3::7] - r[3::7]).max() < 2e-3 * scale, name
 
 
-def forced_pool_forward(o, x, arg_stn, arg_trunk):
-    """Train-mode forward of the restated network (float64) whose two max-pools read the GIVEN point of every
-    (candidate, channel) instead of searching the maximum; returns (logp, pooled values and true maxima)."""
-    def stack(mod, h, relu_out, arg):
-        h = torch.relu(mod.bn1(mod.conv1(h)))
-        h = torch.relu(mod.bn2(mod.conv2(h)))
+def forced_forward(o, x, arg_stn, arg_trunk, masks):
+    """Train-mode forward of the restated network (float64) that takes every non-smooth decision from outside: the
+    two max-pools read the GIVEN point of each (candidate, channel), every ReLU passes where the GIVEN mask is set.
+    Returns (logp, list of (pre-activation, mask) pairs, list of (chosen value, true maximum) pairs)."""
+    B, _, P = x.shape
+    kinks, pools = [], []
+
+    def gate(pre, mask):
+        kinks.append((pre, mask))
+        return pre * mask.to(pre.dtype)
+
+    def rows(m, C):                                     # [B*P, C] rows -> [B, C, P]
+        return m.reshape(B, P, C).permute(0, 2, 1)
+
+    def stack(mod, h, name, arg, relu_out):
+        h = gate(mod.bn1(mod.conv1(h)), rows(masks[name + "_h1"], 64))
+        h = gate(mod.bn2(mod.conv2(h)), rows(masks[name + "_h2"], 128))
         y = mod.bn3(mod.conv3(h))
-        if relu_out:
-            y = torch.relu(y)
-        return y.gather(2, arg.long().unsqueeze(2)).squeeze(2), y.max(dim=2).values
+        v = y.gather(2, arg.long().unsqueeze(2)).squeeze(2)
+        pools.append((v, y.max(dim=2).values))
+        return gate(v, masks[name + "_pooled"]) if relu_out else v
 
     stn = o.feat.stn
-    ps, ms = stack(stn, x, True, arg_stn)
-    h = torch.relu(stn.bn4(stn.fc1(ps)))
-    h = torch.relu(stn.bn5(stn.fc2(h)))
+    ps = stack(stn, x, "stn", arg_stn, True)
+    h = gate(stn.bn4(stn.fc1(ps)), masks["stn_a1"])
+    h = gate(stn.bn5(stn.fc2(h)), masks["stn_a2"])
     iden = torch.eye(3, dtype=x.dtype).reshape(1, 9)
     trans = (stn.fc3(h) + iden).reshape(-1, 3, 3)
     xt = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
-    pt, mt = stack(o.feat, xt, False, arg_trunk)
-    h = torch.relu(o.bn1(o.fc1(pt)))
-    h = torch.relu(o.bn2(o.fc2(h)))
-    return F.log_softmax(o.fc3(h), dim=1), (ps, ms), (pt, mt)
+    pt = stack(o.feat, xt, "trunk", arg_trunk, False)
+    h = gate(o.bn1(o.fc1(pt)), masks["head_a1"])
+    h = gate(o.bn2(o.fc2(h)), masks["head_a2"])
+    return F.log_softmax(o.fc3(h), dim=1), kinks, pools
 
 
-@pytest.mark.parametrize("P,B,k,seed", [(130, 70, 2, 8), (64, 70, 2, 13), (37, 150, 2, 9), (300, 20, 3, 10)])
-def test_gradients_with_the_arg_max_rows_the_kernel_chose(P, B, k, seed):
-    """The max over points makes the gradient discontinuous where two points of a candidate tie to within float32
-    rounding, so two correct implementations may route a channel's gradient to different rows.  This test takes
-    the rows the HIP forward chose, checks that each holds the maximum (to rounding), and compares every gradient
-    with a float64 step of the restated network that is forced onto the same rows: tie-proof, at any shape.
-    What remains are the ReLU kinks: with ~10^6 pre-activations per case a few lie within float32 rounding of zero,
-    and where such a point is also an arg-max row (which concentrates gradient) a mask that falls the other way
-    changes one bias-gradient element by ~1e-2 and everything upstream of it by ~1e-3.  The seeded cases below are
-    ones where float32 and float64 agree on every mask (seed 8 at P=64, B=70 is one where they do not: trunk bn2,
-    candidate 55, channel 48, point 32 sits at -7.8e-7; tools/diag/kink.py shows the error in exactly that
-    channel)."""
+@pytest.mark.parametrize("P,B,k,seed", [(130, 70, 2, 8), (64, 70, 2, 8), (64, 70, 2, 13), (37, 150, 2, 9),
+                                        (300, 20, 3, 10), (750, 24, 2, 11)])
+def test_gradients_with_the_kernels_own_decisions(P, B, k, seed):
+    """A PointNet step is piecewise smooth: the max over points and every ReLU switch where two values tie to within
+    float32 rounding, and with ~10^6 such decisions per step a few always do.  Two correct float32 implementations
+    then differ by O(1e-3 .. 1e-2) in isolated gradient entries and everything upstream of them (seed 8 at P=64,
+    B=70: trunk bn2 of candidate 55, channel 48, point 32 is -7.8e-7), so a plain comparison at realistic sizes
+    tests luck.  This test reads the decisions the HIP forward took - arg-max rows (pngpd_train_argmax) and ReLU
+    masks (signs of the saved activations, pngpd_train_saved) - checks that each is right to rounding (the chosen
+    row holds the maximum, a mask disagrees with the float64 sign only where the pre-activation is ~0), and then
+    compares every gradient with a float64 step of the restated network forced onto the same decisions."""
     from pointnetgpd_amd import training
     gain = 1.3
     x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
@@ -312,15 +324,22 @@ def test_gradients_with_the_arg_max_rows_the_kernel_chose(P, B, k, seed):
     logp, trans, ws, xc = training.train_forward(m, x.cuda())
     loss, dlogp = nll_loss(logp, target.cuda())
     grads = {id(p): torch.zeros_like(p) for p in m.parameters()}
-    training.train_backward(m, xc, logp, dlogp, None, ws, lambda p: grads[id(p)])
     arg_stn, arg_trunk = (a.cpu() for a in training.critical_points(ws, B, P, k))
+    masks = {n: (training.saved_activation(ws, B, P, k, n) > 0).cpu() for n in training.SAVED}
+    training.train_backward(m, xc, logp, dlogp, None, ws, lambda p: grads[id(p)])
     assert int(arg_stn.min()) >= 0 and int(arg_stn.max()) < P and int(arg_trunk.min()) >= 0 and int(arg_trunk.max()) < P
 
     o = po.build_cls(P, k, sd, eval_mode=False).double()
-    ref_logp, (ps, ms), (pt, mt) = forced_pool_forward(o, x.double(), arg_stn, arg_trunk)
-    for chosen, true_max in ((ps, ms), (pt, mt)):          # the chosen row holds the maximum
-        scale = float(true_max.abs().max())
-        assert float((true_max - chosen).max()) < 2e-5 * scale
+    ref_logp, kinks, pools = forced_forward(o, x.double(), arg_stn, arg_trunk, masks)
+    for chosen, true_max in pools:                          # the chosen row holds the maximum
+        assert float((true_max - chosen).max()) < 2e-5 * float(true_max.abs().max())
+    flipped = 0
+    for pre, mask in kinks:                                 # a mask differs from the float64 sign only at ~0
+        wrong = (pre > 0) != mask
+        flipped += int(wrong.sum())
+        if wrong.any():
+            assert float(pre[wrong].abs().max()) < 2e-5 * float(pre.abs().max())
+    print(f"P={P} B={B}: {flipped} ReLU decisions differ from the float64 forward")
     assert (logp.cpu().double() - ref_logp).abs().max().item() < 5e-5
     F.nll_loss(ref_logp, target).backward()
     assert abs(loss.item() - F.nll_loss(ref_logp, target).item()) < 2e-5
@@ -331,6 +350,6 @@ def test_gradients_with_the_arg_max_rows_the_kernel_chose(P, B, k, seed):
         if np.abs(r).max() < 1e-7:
             if np.abs(g).max() >= 1e-5:
                 bad.append((n, float(np.abs(g).max())))
-        elif rel_err(g, r) >= 2e-4:
+        elif rel_err(g, r) >= 1e-4:
             bad.append((n, float(rel_err(g, r))))
     assert not bad, bad
