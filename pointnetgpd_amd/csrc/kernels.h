@@ -91,7 +91,7 @@ hipError_t launch_voxel_unique(const float* pts, int S, int n, void* ws, float* 
 
 // ---- tall-matrix products (tall_gemm.hip) ------------------------------------------------------
 constexpr int TALL_GEMM_MAX_BLOCKS = 512;    // persistent workgroups: two per CU on a 256-CU part
-bool tall_gemm_supports(int M, int N, int K);          // K, N in {64, 128}
+bool tall_gemm_supports(int M, int N, int K);          // (K, N) = (64,128), (128,64) or (128,128)
 int tall_gemm_blocks(int M);                           // workgroups launched = statistic records written
 // Y[M,N] = act(X[M,K] B + bias); B[k][n] = W[k*N+n] (w_is_kn) or W[n*K+k]; bias optional.
 // stat_rec (optional): [tall_gemm_blocks(M)][N][3] doubles (count, mean, sum of squared deviations) of the columns of

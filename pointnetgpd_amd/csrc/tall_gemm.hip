@@ -1,6 +1,6 @@
 // Products of a very tall matrix with a small one, exact f32 on v_mfma_f32_32x32x2_f32:
 //
-//     Y[M,N] = act(X[M,K] B[K,N] + bias),   K, N in {64, 128},  M = candidates x points (10^5 .. 10^6)
+//     Y[M,N] = act(X[M,K] B[K,N] + bias),   (K, N) = (64,128), (128,64), (128,128),  M = candidates x points
 //
 // used by the training step for the per-point layers (conv1d with kernel 1 = a row-wise linear map,
 // model/pointnet.py:30-31, :143-146, and their input gradients).  Such a product moves ~1 KB per row and does
@@ -223,14 +223,13 @@ int tall_gemm_blocks(int M) {
 }
 
 bool tall_gemm_supports(int M, int N, int K) {
-    return M >= 1 && (N == 64 || N == 128) && (K == 64 || K == 128);
+    return M >= 1 && (N == 64 || N == 128) && (K == 64 || K == 128) && !(N == 64 && K == 64);
 }
 
 hipError_t launch_tall_gemm(const float* X, const float* W, int w_is_kn, const float* bias, float* Y, int M, int N,
                             int K, int relu, double* stat_rec, hipStream_t s) {
     if (!X || !W || !Y || !tall_gemm_supports(M, N, K)) return hipErrorInvalidValue;
     const int blocks = tall_gemm_blocks(M);
-    if (K == 64 && N == 64) return launch_one<64, 64>(X, W, w_is_kn, bias, Y, M, relu, stat_rec, blocks, s);
     if (K == 64 && N == 128) return launch_one<64, 128>(X, W, w_is_kn, bias, Y, M, relu, stat_rec, blocks, s);
     if (K == 128 && N == 64) return launch_one<128, 64>(X, W, w_is_kn, bias, Y, M, relu, stat_rec, blocks, s);
     return launch_one<128, 128>(X, W, w_is_kn, bias, Y, M, relu, stat_rec, blocks, s);
