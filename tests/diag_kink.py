@@ -1,6 +1,6 @@
 """Hand-run: which elements of feat.bn2.bias / feat.bn1.bias differ most from the float32 oracle (P B k seed)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.nn.functional as F
 from oracle import pointnet_oracle as po
 from pointnetgpd_amd import synth

@@ -1,5 +1,5 @@
 """Hand-run diagnostic: per-parameter gradient error and Adam sign flips of one training step against the
-CPU oracle (python tools/debug_train.py [P k seed B gain])."""
+CPU oracle (python tests/diag_train_step.py [P k seed B gain])."""
 import os
 import sys
 

@@ -209,7 +209,7 @@ def test_gradients_and_statistics_at_odd_shapes(P, B, k, seed):
     (The max over points and the ReLUs make the gradient discontinuous: where two points tie, or a pre-activation
     sits at zero, to within float32 rounding, two correct float32 implementations differ in isolated elements.
     These small seeded cases stay clear of that; larger ones are covered by the tie-proof test below, and
-    tools/debug_train.py compares both implementations with a float64 step.)"""
+    tests/diag_train_step.py compares both implementations with a float64 step.)"""
     gain = 1.3
     x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
     target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) * k).astype(np.int64))
