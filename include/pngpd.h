@@ -132,8 +132,9 @@ int pngpd_score(const float* logp_dev, int B, int k, float* probs_dev, int64_t* 
  *                               p[8].x, p[4].x of the gripper corner table (:323, 332-337)
  *
  * Call order: pngpd_crop_count -> (read offsets_dev[G] = total, size idx_dev) -> pngpd_crop_emit
- * -> pngpd_crop_gather.  The three calls share `workspace_dev` (normalised frames + one bit per
- * (grasp, point)); it must stay untouched between them.
+ * -> pngpd_crop_gather.  The three calls share `workspace_dev` (normalised frames + the scene binned into
+ * a uniform grid); it must stay untouched between them.  pngpd_crop_emit takes the same `limits` and the
+ * counts pngpd_crop_count wrote.
  * ------------------------------------------------------------------------------------------ */
 size_t pngpd_crop_workspace_bytes(int S, int G);
 
@@ -158,9 +159,9 @@ int pngpd_crop_count_frames(const float* scene_dev, int S, const double* frames_
  * offsets[g] .. offsets[g+1]-1 (in_ind_, :413); entries at or beyond idx_capacity are dropped.
  * pts_g_dev (optional) float64 [idx_capacity,3]: the same points in the gripper frame
  * (in_ind_points_, :423). */
-int pngpd_crop_emit(const float* scene_dev, int S, int G, const void* workspace_dev,
-                    size_t workspace_bytes, const int64_t* offsets_dev, int32_t* idx_dev,
-                    int64_t idx_capacity, double* pts_g_dev, void* stream);
+int pngpd_crop_emit(const float* scene_dev, int S, int G, const double* limits, const void* workspace_dev,
+                    size_t workspace_bytes, const int32_t* cnt_dev, const int64_t* offsets_dev,
+                    int32_t* idx_dev, int64_t idx_capacity, double* pts_g_dev, void* stream);
 
 /*
  * Subsample / pad every grasp to P points, `repeat` times (apps/kinect2grasp.py:746-774), and

@@ -43,8 +43,8 @@ SIGNATURES = {
     "pngpd_crop_workspace_bytes": (c_size_t, [c_int, c_int]),
     "pngpd_crop_count": (c_int, [c_void_p, c_int, c_void_p, c_int, POINTER(c_double), c_void_p, c_size_t, c_void_p,
                                  c_void_p, c_void_p]),
-    "pngpd_crop_emit": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int64, c_void_p,
-                                c_void_p]),
+    "pngpd_crop_emit": (c_int, [c_void_p, c_int, c_int, POINTER(c_double), c_void_p, c_size_t, c_void_p, c_void_p,
+                                c_void_p, c_int64, c_void_p, c_void_p]),
     "pngpd_crop_gather": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_void_p, c_uint64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pngpd_crop_count_frames": (c_int, [c_void_p, c_int, c_void_p, c_int, POINTER(c_double), c_void_p, c_size_t,

@@ -333,16 +333,32 @@ int pngpd_forward_infer_timed(const pngpd_model* m, const float* x_dev, int layo
     return rc;
 }
 
-// crop workspace: [G,12] f64 frames, then [G, Wp] u64 mask (frames region rounded up to 256 B)
+// crop workspace: [G,12] f64 frames | the scene's spatial grid | only in the all-pairs test mode a [G, Wp] u64
+// mask.  Every region is rounded up to 256 B.
 static size_t crop_frames_bytes(int G) { return ((size_t)G * 12 * sizeof(double) + 255) & ~(size_t)255; }
 
 static size_t crop_mask_bytes(int S, int G) {
+    if (!pngpd::crop_brute_mode()) return 0;
     return ((size_t)G * pngpd::crop_words_per_grasp(S) * sizeof(unsigned long long) + 255) & ~(size_t)255;
 }
 
+namespace {
+struct CropWs {
+    double* frames;
+    void* grid;
+    unsigned long long* mask;
+    CropWs(const void* base, int S, int G) {
+        char* p = (char*)base;
+        frames = (double*)p;              p += crop_frames_bytes(G);
+        grid = p;                         p += pngpd::crop_grid_bytes(S);
+        mask = pngpd::crop_brute_mode() ? (unsigned long long*)p : nullptr;
+    }
+};
+}  // namespace
+
 size_t pngpd_crop_workspace_bytes(int S, int G) {
     if (S < 1 || G < 1) return 0;
-    return crop_frames_bytes(G) + crop_mask_bytes(S, G) + pngpd::crop_grid_bytes(S);
+    return crop_frames_bytes(G) + pngpd::crop_grid_bytes(S) + crop_mask_bytes(S, G);
 }
 
 static int crop_ws_check(int S, int G, const void* ws, size_t bytes) {
@@ -361,10 +377,8 @@ int pngpd_crop_count(const float* scene_dev, int S, const double* grasps_dev, in
     int rc = crop_ws_check(S, G, workspace_dev, workspace_bytes);
     if (rc) return rc;
     pngpd::CropLimits L{limits[0], limits[1], limits[2], limits[3], limits[4], limits[5]};
-    double* frames = (double*)workspace_dev;
-    auto* mask = (unsigned long long*)((char*)workspace_dev + crop_frames_bytes(G));
-    void* grid_ws = (char*)workspace_dev + crop_frames_bytes(G) + crop_mask_bytes(S, G);
-    HIP_TRY(pngpd::launch_crop_count(scene_dev, S, grasps_dev, G, L, frames, mask, grid_ws, cnt_dev,
+    CropWs w(workspace_dev, S, G);
+    HIP_TRY(pngpd::launch_crop_count(scene_dev, S, grasps_dev, G, L, w.frames, w.mask, w.grid, cnt_dev,
                                      (long long*)offsets_dev, (hipStream_t)stream));
     return PNGPD_OK;
 }
@@ -377,25 +391,24 @@ int pngpd_crop_count_frames(const float* scene_dev, int S, const double* frames_
     int rc = crop_ws_check(S, G, workspace_dev, workspace_bytes);
     if (rc) return rc;
     pngpd::CropLimits L{limits[0], limits[1], limits[2], limits[3], limits[4], limits[5]};
-    double* frames = (double*)workspace_dev;
-    auto* mask = (unsigned long long*)((char*)workspace_dev + crop_frames_bytes(G));
-    void* grid_ws = (char*)workspace_dev + crop_frames_bytes(G) + crop_mask_bytes(S, G);
-    HIP_TRY(pngpd::launch_crop_count(scene_dev, S, frames_dev, G, L, frames, mask, grid_ws, cnt_dev,
+    CropWs w(workspace_dev, S, G);
+    HIP_TRY(pngpd::launch_crop_count(scene_dev, S, frames_dev, G, L, w.frames, w.mask, w.grid, cnt_dev,
                                      (long long*)offsets_dev, (hipStream_t)stream, true));
     return PNGPD_OK;
 }
 
-int pngpd_crop_emit(const float* scene_dev, int S, int G, const void* workspace_dev, size_t workspace_bytes,
-                    const int64_t* offsets_dev, int32_t* idx_dev, int64_t idx_capacity, double* pts_g_dev,
-                    void* stream) {
-    if (!scene_dev || !offsets_dev || !idx_dev) return fail(PNGPD_ERR_INVALID, "pngpd_crop_emit: NULL argument");
+int pngpd_crop_emit(const float* scene_dev, int S, int G, const double* limits, const void* workspace_dev,
+                    size_t workspace_bytes, const int32_t* cnt_dev, const int64_t* offsets_dev, int32_t* idx_dev,
+                    int64_t idx_capacity, double* pts_g_dev, void* stream) {
+    if (!scene_dev || !limits || !cnt_dev || !offsets_dev || !idx_dev)
+        return fail(PNGPD_ERR_INVALID, "pngpd_crop_emit: NULL argument");
     if (idx_capacity < 0) return fail(PNGPD_ERR_SHAPE, "pngpd_crop_emit: negative capacity");
     int rc = crop_ws_check(S, G, workspace_dev, workspace_bytes);
     if (rc) return rc;
-    const double* frames = (const double*)workspace_dev;
-    auto* mask = (const unsigned long long*)((const char*)workspace_dev + crop_frames_bytes(G));
-    HIP_TRY(pngpd::launch_crop_emit(scene_dev, S, G, frames, mask, (const long long*)offsets_dev, idx_dev,
-                                    idx_capacity, pts_g_dev, (hipStream_t)stream));
+    pngpd::CropLimits L{limits[0], limits[1], limits[2], limits[3], limits[4], limits[5]};
+    CropWs w(workspace_dev, S, G);
+    HIP_TRY(pngpd::launch_crop_emit(scene_dev, S, G, L, w.frames, w.mask, w.grid, cnt_dev, (const long long*)offsets_dev,
+                                    idx_dev, idx_capacity, pts_g_dev, (hipStream_t)stream));
     return PNGPD_OK;
 }
 

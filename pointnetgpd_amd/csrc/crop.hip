@@ -8,14 +8,13 @@
 //     pg[r] = fma(R[r][2], d2, fma(R[r][1], d1, R[r][0]*d0))
 // and contraction of separate multiplies and adds is switched off for this file.
 //
-// Pipeline (all on one stream, no atomics, so the output order is the ascending point index):
+// Pipeline (all on one stream; the output order is the ascending point index, as np.where gives it):
 //   frames : normalised frame per grasp                          [G,12] f64 in the workspace
-//   mask   : brute-force box test, one bit per (grasp, point)    [G, Wp] u64 in the workspace
-//            each thread keeps 4 points in registers and walks a block of grasps whose frames
-//            arrive through the scalar cache; wave ballots are staged in LDS and written as
-//            whole 128-byte rows
-//   count  : popcount per grasp, then an exclusive scan over grasps
-//   emit   : per grasp, block-scan of popcounts + bit expansion -> ascending indices
+//   count  : points inside the region per grasp, then an exclusive scan over grasps
+//   emit   : ascending scene indices (+ float64 gripper-frame points) per grasp
+//            both through the spatial grid of crop_grid.hip.  The all-pairs variant below (one bit per
+//            (grasp, point) in a [G, Wp] u64 mask, popcount, bit expansion) is kept as the cross-check the
+//            tests run with PNGPD_CROP_BRUTE=1.
 //   gather : subsample / pad to P points per (grasp, repeat), transform to the gripper frame,
 //            round to float32 = the network input of main_test.py:74-76
 #include <hip/hip_runtime.h>
@@ -275,40 +274,47 @@ int crop_words_per_grasp(int S) {
     return tiles * (CROP_TILE / 64);
 }
 
+bool crop_brute_mode() {
+    const char* v = getenv("PNGPD_CROP_BRUTE");
+    return v && v[0] == '1';
+}
+
 hipError_t launch_crop_count(const float* scene, int S, const double* grasps, int G, const CropLimits& L,
                              double* frames, unsigned long long* mask, void* grid_ws, int* cnt,
                              long long* offsets, hipStream_t s, bool frames_given) {
-    if (!scene || !grasps || !frames || !mask || !grid_ws || !cnt || !offsets || S < 1 || G < 1)
-        return hipErrorInvalidValue;
-    const int Wp = crop_words_per_grasp(S);
+    if (!scene || !grasps || !frames || !grid_ws || !cnt || !offsets || S < 1 || G < 1) return hipErrorInvalidValue;
     if (frames_given) {   // `grasps` already is [G,12]: origin + the three matrix rows, used as they are
         hipError_t e = hipMemcpyAsync(frames, grasps, (size_t)G * 12 * sizeof(double), hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return e;
     } else {
         hipLaunchKernelGGL(crop_frames_kernel, dim3((G + 255) / 256), dim3(256), 0, s, grasps, frames, G);
     }
-    // PNGPD_CROP_BRUTE=1 keeps the all-pairs pass (used by the tests to cross-check the culled one)
-    const char* brute_env = getenv("PNGPD_CROP_BRUTE");
-    const bool brute = brute_env && brute_env[0] == '1';
-    if (brute) {
+    if (crop_brute_mode()) {
+        if (!mask) return hipErrorInvalidValue;
+        const int Wp = crop_words_per_grasp(S);
         dim3 grid((S + CROP_TILE - 1) / CROP_TILE, (G + CROP_GB - 1) / CROP_GB);
         hipLaunchKernelGGL(crop_mask_kernel, grid, dim3(256), 0, s, scene, S, frames, G, L, mask, Wp);
+        hipLaunchKernelGGL(crop_count_kernel, dim3(G), dim3(256), 0, s, mask, Wp, cnt);
     } else {
-        hipError_t e = launch_crop_mask_grid(scene, S, (const double*)frames, G, L, mask, Wp, grid_ws, s);
+        hipError_t e = launch_crop_count_grid(scene, S, (const double*)frames, G, L, grid_ws, cnt, s);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(crop_count_kernel, dim3(G), dim3(256), 0, s, mask, Wp, cnt);
     hipLaunchKernelGGL(crop_offsets_kernel, dim3(1), dim3(256), 0, s, cnt, G, offsets);
     return hipGetLastError();
 }
 
-hipError_t launch_crop_emit(const float* scene, int S, int G, const double* frames,
-                            const unsigned long long* mask, const long long* offsets, int* idx,
-                            long long capacity, double* pts_g, hipStream_t s) {
-    if (!scene || !frames || !mask || !offsets || !idx || S < 1 || G < 1 || capacity < 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(crop_emit_kernel, dim3(G), dim3(256), 0, s, mask, crop_words_per_grasp(S), offsets, scene,
-                       frames, idx, capacity, pts_g);
-    return hipGetLastError();
+hipError_t launch_crop_emit(const float* scene, int S, int G, const CropLimits& L, const double* frames,
+                            const unsigned long long* mask, const void* grid_ws, const int* cnt,
+                            const long long* offsets, int* idx, long long capacity, double* pts_g, hipStream_t s) {
+    if (!scene || !frames || !grid_ws || !cnt || !offsets || !idx || S < 1 || G < 1 || capacity < 0)
+        return hipErrorInvalidValue;
+    if (crop_brute_mode()) {
+        if (!mask) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(crop_emit_kernel, dim3(G), dim3(256), 0, s, mask, crop_words_per_grasp(S), offsets, scene,
+                           frames, idx, capacity, pts_g);
+        return hipGetLastError();
+    }
+    return launch_crop_emit_grid(scene, S, frames, G, L, grid_ws, cnt, offsets, idx, capacity, pts_g, s);
 }
 
 hipError_t launch_crop_gather(const float* scene, const double* frames, const int* idx, const long long* offsets,

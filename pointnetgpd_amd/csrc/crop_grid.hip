@@ -2,15 +2,18 @@
 // is binned once per frame into a uniform grid and each grasp only visits the cells that the
 // bounding box of its gripper region overlaps.  The inside test itself is unchanged (crop_math.h,
 // float64, reference operation order), and the culling is conservative (box corners in float64
-// plus a 1 um margin; cell coordinates are a monotone function of the coordinate), so the set of
-// points that pass is exactly the set the brute-force pass finds.  Hits are recorded as bits of
-// the per-grasp mask, which keeps the ascending-index order of np.where for free.
+// plus a 1 um margin; cell coordinates are a monotone function of the coordinate; within that box a row of
+// cells is narrowed to the cells whose centre maps to within half a cell diagonal of the region), so the set of
+// points that pass is exactly the set the brute-force pass finds.  Nothing of size G x S is ever written:
+// a first traversal counts the hits of every grasp, a second one collects them (~800 per grasp at the online
+// sizes) in LDS, sorts them there - np.where order is ascending - and writes the index and point lists.
 //
 //   bounds  : min/max of the scene                      -> grid origin, cell size, dimensions
 //   count   : cell of every point + histogram (atomics)
 //   scan    : exclusive prefix over the (at most 64^3) cells
 //   scatter : points regrouped by cell as float4 {x, y, z, original index}
-//   cull    : one wave per grasp; x-runs of cells are contiguous in the regrouped array
+//   cull    : twice - count (one wave per grasp), emit (one workgroup per grasp); x-runs of cells are contiguous
+//             in the regrouped array
 #include <hip/hip_runtime.h>
 
 #include "crop_math.h"
@@ -100,34 +103,52 @@ __global__ void k_cell_count(const float* __restrict__ scene, int S, const GridP
     atomicAdd(&hist[cell], 1);
 }
 
-// exclusive scan of hist over the cells in use into start[0..ncells]; cursor = copy. One block of 1024.
+// exclusive scan of hist over the cells in use into start[0..ncells]; cursor = copy.  One block of 1024 threads
+// walks the cells in chunks of 4096 (one int4 per thread: coalesced) and carries the running total.
 __global__ __launch_bounds__(1024) void k_scan_cells(const GridParams* __restrict__ gp, const int* __restrict__ hist,
                                                      int* __restrict__ start, int* __restrict__ cursor) {
     __shared__ int s_wave[16];
     const int ncells = gp->dim[0] * gp->dim[1] * gp->dim[2];
-    const int PER = (ncells + 1023) / 1024;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int base = tid * PER;
-    const int n_mine = max(0, min(PER, ncells - base));
-    int sum = 0;
-    for (int i = 0; i < n_mine; ++i) sum += hist[base + i];
-    int inc = sum;
+    int carry = 0;
+    for (int c0 = 0; c0 < ncells; c0 += 4096) {
+        const int base = c0 + 4 * tid;
+        int4 h = make_int4(0, 0, 0, 0);
+        if (base + 3 < ncells) {
+            h = *(const int4*)(hist + base);          // hist is 256-byte aligned and base a multiple of 4
+        } else {
+            if (base < ncells) h.x = hist[base];
+            if (base + 1 < ncells) h.y = hist[base + 1];
+            if (base + 2 < ncells) h.z = hist[base + 2];
+        }
+        const int sum = h.x + h.y + h.z + h.w;
+        int inc = sum;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        __syncthreads();                              // s_wave of the previous chunk has been read
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        int before = carry, total = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int v = s_wave[w];
+            if (w < wave) before += v;
+            total += v;
+        }
+        int run = before + inc - sum;
+        const int v[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (base + i < ncells) {
+                start[base + i] = run;
+                cursor[base + i] = run;
+                run += v[i];
+            }
+        carry += total;
     }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    int before = 0;
-    for (int w = 0; w < wave; ++w) before += s_wave[w];
-    int run = before + inc - sum;
-    for (int i = 0; i < n_mine; ++i) {
-        start[base + i] = run;
-        cursor[base + i] = run;
-        run += hist[base + i];
-    }
-    if (n_mine > 0 && base + n_mine == ncells) start[ncells] = run;
+    if (tid == 0) start[ncells] = carry;
 }
 
 __global__ void k_scatter(const float* __restrict__ scene, int S, const int* __restrict__ cell_of,
@@ -139,16 +160,19 @@ __global__ void k_scatter(const float* __restrict__ scene, int S, const int* __r
                               __int_as_float(s));
 }
 
-// one wave per grasp
-__global__ __launch_bounds__(256) void k_cull(const double* __restrict__ frames, int G, CropLimits L,
-                                              const GridParams* __restrict__ gp, const int* __restrict__ start,
-                                              const float4* __restrict__ sorted,
-                                              unsigned long long* __restrict__ mask, int Wp) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= G) return;
-    const double* f = frames + (size_t)g * 12;
-    // bounding box of the gripper region in the world: corners c + x*a + y*b + z*m
+// ---------------------------------------------------------------------------------------------
+// culled traversal: one wave per grasp
+// ---------------------------------------------------------------------------------------------
+// Cells the axis-aligned bounding box of the gripper region overlaps, and per frame row r the slack
+// |row_r| * (half a cell diagonal): a point of a cell maps to within that slack of the cell centre's image.
+struct GraspCells {
+    int c0[3], c1[3];
+    double slack[3];
+};
+
+__device__ __forceinline__ GraspCells grasp_cells(const double* __restrict__ f, const CropLimits& L,
+                                                  const GridParams* __restrict__ gp) {
+    GraspCells gc;
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int k = 0; k < 8; ++k) {
         const double x = (k & 1) ? L.xhi : L.xlo, y = (k & 2) ? L.yhi : L.ylo, z = (k & 4) ? L.zhi : L.zlo;
@@ -158,27 +182,205 @@ __global__ __launch_bounds__(256) void k_cull(const double* __restrict__ frames,
             hi[c] = fmax(hi[c], w);
         }
     }
-    int c0[3], c1[3];
     for (int c = 0; c < 3; ++c) {
         const double margin = 1e-6 + 1e-9 * (fabs(lo[c]) + fabs(hi[c]));
-        c0[c] = cell_coord(lo[c] - margin, gp->origin[c], gp->inv_cell, gp->dim[c]);
-        c1[c] = cell_coord(hi[c] + margin, gp->origin[c], gp->inv_cell, gp->dim[c]);
+        gc.c0[c] = cell_coord(lo[c] - margin, gp->origin[c], gp->inv_cell, gp->dim[c]);
+        gc.c1[c] = cell_coord(hi[c] + margin, gp->origin[c], gp->inv_cell, gp->dim[c]);
     }
-    const int dx = gp->dim[0], dy = gp->dim[1];
-    unsigned long long* row = mask + (size_t)g * Wp;
-    for (int iz = c0[2]; iz <= c1[2]; ++iz)
-        for (int iy = c0[1]; iy <= c1[1]; ++iy) {
-            const int cb = dx * (iy + dy * iz);
-            const int p0 = start[cb + c0[0]], p1 = start[cb + c1[0] + 1];
-            for (int p = p0 + lane; p < p1; p += 64) {
-                const float4 v = sorted[p];
-                const PointD q = to_gripper(f, (double)v.x, (double)v.y, (double)v.z);
-                if (in_box(q, L)) {
-                    const int s = __float_as_int(v.w);
-                    atomicOr(&row[s >> 6], 1ull << (s & 63));
+    const double cell = 1.0 / gp->inv_cell;
+    const double half_diag = 0.8660254037844387 * cell * (1.0 + 1e-6) + 1e-6;   // + rounding of the cell assignment
+    for (int r = 0; r < 3; ++r) {
+        const double a = f[3 + 3 * r], b = f[4 + 3 * r], c = f[5 + 3 * r];
+        gc.slack[r] = sqrt(a * a + b * b + c * c) * half_diag;
+    }
+    return gc;
+}
+
+// Range [p0, p1) of the cell-sorted points of row (iy, iz) that can hold a hit: lane l looks at cell c0x + l
+// (a row has at most GRID_MAX_DIM = 64 cells) and keeps it when the cell centre's image lies within the box
+// widened by the slack; the run from the first to the last kept cell is contiguous in the sorted array.
+// The grid of a clamped scene is exact at its border cells too: every point lies inside the grid's bounds.
+__device__ __forceinline__ bool row_range(const double* __restrict__ f, const CropLimits& L, const GraspCells& gc,
+                                          const GridParams* __restrict__ gp, const int* __restrict__ start, int iy,
+                                          int iz, int lane, int& p0, int& p1) {
+    const int ix = gc.c0[0] + lane;
+    const double cell = 1.0 / gp->inv_cell;
+    bool keep = false;
+    if (ix <= gc.c1[0]) {
+        const PointD q = to_gripper(f, gp->origin[0] + (ix + 0.5) * cell, gp->origin[1] + (iy + 0.5) * cell,
+                                    gp->origin[2] + (iz + 0.5) * cell);
+        keep = (q.x > L.xlo - gc.slack[0]) & (q.x < L.xhi + gc.slack[0]) & (q.y > L.ylo - gc.slack[1]) &
+               (q.y < L.yhi + gc.slack[1]) & (q.z > L.zlo - gc.slack[2]) & (q.z < L.zhi + gc.slack[2]);
+    }
+    const unsigned long long kept = __ballot(keep);
+    if (kept == 0ull) return false;
+    const int first = __ffsll((long long)kept) - 1, last = 63 - __clzll((long long)kept);
+    const int cb = gp->dim[0] * (iy + gp->dim[1] * iz) + gc.c0[0];
+    p0 = start[cb + first];
+    p1 = start[cb + last + 1];
+    return p0 < p1;
+}
+
+// cnt[g] = points inside the gripper region
+__global__ __launch_bounds__(256) void k_cull_count(const double* __restrict__ frames, int G, CropLimits L,
+                                                    const GridParams* __restrict__ gp, const int* __restrict__ start,
+                                                    const float4* __restrict__ sorted, int* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const double* f = frames + (size_t)g * 12;
+    const GraspCells gc = grasp_cells(f, L, gp);
+    int n = 0;
+    for (int iz = gc.c0[2]; iz <= gc.c1[2]; ++iz)
+        for (int iy = gc.c0[1]; iy <= gc.c1[1]; ++iy) {
+            int p0, p1;
+            if (!row_range(f, L, gc, gp, start, iy, iz, lane, p0, p1)) continue;
+            for (int p = p0; p < p1; p += 64) {           // wave-uniform trip count: ballots stay whole
+                bool hit = false;
+                if (p + lane < p1) {
+                    const float4 v = sorted[p + lane];
+                    hit = in_box(to_gripper(f, (double)v.x, (double)v.y, (double)v.z), L);
                 }
+                n += __popcll(__ballot(hit));
             }
         }
+    if (lane == 0) cnt[g] = n;
+}
+
+// Ascending sort of list[0..n) by a 256-thread block: a bitonic network whose comparators all point the same way
+// (the first step of every merge mirrors the partner), so the missing tail of a non-power-of-two n acts as +inf.
+__device__ __forceinline__ void block_sort(int* list, int n, int tid) {
+    int log_n2 = 0;
+    while ((1 << log_n2) < n) ++log_n2;
+    const int half = (1 << log_n2) >> 1;
+    for (int lk = 1; lk <= log_n2; ++lk) {
+        const int k = 1 << lk;
+        for (int lj = lk - 1; lj >= 0; --lj) {
+            const int j = 1 << lj;
+            const bool mirror = (lj == lk - 1);
+            for (int t = tid; t < half; t += 256) {
+                const int i = ((t >> lj) << (lj + 1)) | (t & (j - 1));
+                const int l = mirror ? ((i & ~(k - 1)) | (k - 1 - (i & (k - 1)))) : i + j;
+                if (l < n) {
+                    const int a = list[i], b = list[l];
+                    if (a > b) {
+                        list[i] = b;
+                        list[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+constexpr int CULL_CAP = 4096;               // hits a workgroup sorts in LDS; also the words of its fallback bitmap
+
+// idx[offsets[g] ..] = ascending scene indices of the points inside the gripper region, pts_g = the same points
+// in the gripper frame (float64).  One workgroup per grasp; its four waves share the rows of cells.  Up to
+// CULL_CAP hits are collected in LDS in the order they are found and sorted there; a grasp with more goes over
+// the scene's index range in slabs of 32*CULL_CAP indices, marks the hits of a slab in an LDS bitmap and expands
+// it - ascending by construction.
+__global__ __launch_bounds__(256) void k_cull_emit(const float* __restrict__ scene, int S,
+                                                   const double* __restrict__ frames, int G, CropLimits L,
+                                                   const GridParams* __restrict__ gp, const int* __restrict__ start,
+                                                   const float4* __restrict__ sorted, const int* __restrict__ cnt,
+                                                   const long long* __restrict__ offsets, int* __restrict__ idx,
+                                                   long long capacity, double* __restrict__ pts_g) {
+    __shared__ int list[CULL_CAP];
+    __shared__ int s_fill;
+    __shared__ int s_scan[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const int n = cnt[g];
+    if (n == 0) return;
+    const double* f = frames + (size_t)g * 12;
+    const GraspCells gc = grasp_cells(f, L, gp);
+    const long long base = offsets[g];
+    const int ny = gc.c1[1] - gc.c0[1] + 1, nrows = ny * (gc.c1[2] - gc.c0[2] + 1);
+    auto write_out = [&](long long o, int s) {
+        if (o >= capacity) return;
+        idx[o] = s;
+        if (pts_g != nullptr) {
+            const float* p = scene + (size_t)s * 3;
+            const PointD q = to_gripper(f, (double)p[0], (double)p[1], (double)p[2]);
+            pts_g[3 * o + 0] = q.x;
+            pts_g[3 * o + 1] = q.y;
+            pts_g[3 * o + 2] = q.z;
+        }
+    };
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (n <= CULL_CAP) {
+        if (tid == 0) s_fill = 0;
+        __syncthreads();
+        for (int row = wave; row < nrows; row += 4) {
+            const int iy = gc.c0[1] + row % ny, iz = gc.c0[2] + row / ny;
+            int p0, p1;
+            if (!row_range(f, L, gc, gp, start, iy, iz, lane, p0, p1)) continue;
+            for (int p = p0; p < p1; p += 64) {           // wave-uniform trip count: ballots stay whole
+                bool hit = false;
+                int s = 0;
+                if (p + lane < p1) {
+                    const float4 v = sorted[p + lane];
+                    hit = in_box(to_gripper(f, (double)v.x, (double)v.y, (double)v.z), L);
+                    s = __float_as_int(v.w);
+                }
+                const unsigned long long bal = __ballot(hit);
+                if (bal == 0ull) continue;
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&s_fill, __popcll(bal));
+                at = __shfl(at, 0);
+                if (hit) list[at + __popcll(bal & below)] = s;
+            }
+        }
+        __syncthreads();
+        block_sort(list, n, tid);
+        for (int i = tid; i < n; i += 256) write_out(base + i, list[i]);
+        return;
+    }
+    long long o = base;
+    for (int lo = 0; lo < S; lo += 32 * CULL_CAP) {
+        for (int w = tid; w < CULL_CAP; w += 256) list[w] = 0;
+        __syncthreads();
+        for (int row = wave; row < nrows; row += 4) {
+            const int iy = gc.c0[1] + row % ny, iz = gc.c0[2] + row / ny;
+            int p0, p1;
+            if (!row_range(f, L, gc, gp, start, iy, iz, lane, p0, p1)) continue;
+            for (int p = p0 + lane; p < p1; p += 64) {
+                const float4 v = sorted[p];
+                const int s = __float_as_int(v.w) - lo;
+                if (s >= 0 && s < 32 * CULL_CAP && in_box(to_gripper(f, (double)v.x, (double)v.y, (double)v.z), L))
+                    atomicOr((unsigned int*)&list[s >> 5], 1u << (s & 31));
+            }
+        }
+        __syncthreads();
+        for (int w0 = 0; w0 < CULL_CAP; w0 += 256) {
+            unsigned int word = (unsigned int)list[w0 + tid];
+            const int mine = __popc(word);
+            int inc = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(inc, off);
+                if (lane >= off) inc += t;
+            }
+            __syncthreads();                          // s_scan of the previous chunk has been read
+            if (lane == 63) s_scan[wave] = inc;
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < 4; ++w) {
+                if (w < wave) before += s_scan[w];
+                total += s_scan[w];
+            }
+            long long at = o + before + inc - mine;
+            while (word) {
+                const int b = __ffs((int)word) - 1;
+                word &= word - 1;
+                write_out(at++, lo + (w0 + tid) * 32 + b);
+            }
+            o += total;
+        }
+        __syncthreads();
+    }
 }
 
 size_t crop_grid_bytes(int S) {
@@ -188,35 +390,59 @@ size_t crop_grid_bytes(int S) {
            3 * r(((size_t)GRID_CELLS + 1) * sizeof(int)) + r((size_t)S * sizeof(float4));
 }
 
-// Fills the per-grasp mask with the grid-culled exact test.  `grid_ws` holds crop_grid_bytes(S) bytes.
-hipError_t launch_crop_mask_grid(const float* scene, int S, const double* frames, int G, const CropLimits& L,
-                                 unsigned long long* mask, int Wp, void* grid_ws, hipStream_t s) {
-    auto r = [](size_t n) { return (n + 255) & ~(size_t)255; };
+namespace {
+struct GridWs {
+    GridParams* gp;
+    float* part;
+    int *cell_of, *hist, *start, *cursor;
+    float4* sorted;
+    GridWs(void* grid_ws, int S) {
+        auto r = [](size_t n) { return (n + 255) & ~(size_t)255; };
+        const int nblk = (S + BOUNDS_BLOCK_PTS - 1) / BOUNDS_BLOCK_PTS;
+        char* p = (char*)grid_ws;
+        gp = (GridParams*)p;          p += r(sizeof(GridParams));
+        part = (float*)p;             p += r((size_t)nblk * 6 * sizeof(float));
+        cell_of = (int*)p;            p += r((size_t)S * sizeof(int));
+        hist = (int*)p;               p += r(((size_t)GRID_CELLS + 1) * sizeof(int));
+        start = (int*)p;              p += r(((size_t)GRID_CELLS + 1) * sizeof(int));
+        cursor = (int*)p;             p += r(((size_t)GRID_CELLS + 1) * sizeof(int));
+        sorted = (float4*)p;
+    }
+};
+}  // namespace
+
+// Bins the scene and counts, per grasp, the points inside the gripper region.  `grid_ws` holds
+// crop_grid_bytes(S) bytes and keeps the binned scene for launch_crop_emit_grid.
+hipError_t launch_crop_count_grid(const float* scene, int S, const double* frames, int G, const CropLimits& L,
+                                  void* grid_ws, int* cnt, hipStream_t s) {
     const int nblk = (S + BOUNDS_BLOCK_PTS - 1) / BOUNDS_BLOCK_PTS;
-    char* p = (char*)grid_ws;
-    GridParams* gp = (GridParams*)p;              p += r(sizeof(GridParams));
-    float* part = (float*)p;                      p += r((size_t)nblk * 6 * sizeof(float));
-    int* cell_of = (int*)p;                       p += r((size_t)S * sizeof(int));
-    int* hist = (int*)p;                          p += r(((size_t)GRID_CELLS + 1) * sizeof(int));
-    int* start = (int*)p;                         p += r(((size_t)GRID_CELLS + 1) * sizeof(int));
-    int* cursor = (int*)p;                        p += r(((size_t)GRID_CELLS + 1) * sizeof(int));
-    float4* sorted = (float4*)p;
+    GridWs w(grid_ws, S);
     const double ext_x = L.xhi - L.xlo, ext_y = L.yhi - L.ylo, ext_z = L.zhi - L.zlo;
-    double cell_req = fmax(ext_x, fmax(ext_y, ext_z)) * 0.25;
+    // cells of an eighth of the region's longest side (the scene's extent / 63 if that is larger)
+    double cell_req = fmax(ext_x, fmax(ext_y, ext_z)) * 0.125;
     if (!(cell_req > 0.0)) cell_req = 1e-3;
-    hipError_t e = hipMemsetAsync(mask, 0, (size_t)G * Wp * sizeof(unsigned long long), s);
+    hipError_t e = hipMemsetAsync(w.hist, 0, ((size_t)GRID_CELLS + 1) * sizeof(int), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(hist, 0, ((size_t)GRID_CELLS + 1) * sizeof(int), s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bounds_partial, dim3(nblk), dim3(256), 0, s, scene, S, part);
-    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(256), 0, s, (const float*)part, nblk, cell_req, gp);
-    hipLaunchKernelGGL(k_cell_count, dim3((S + 255) / 256), dim3(256), 0, s, scene, S, (const GridParams*)gp, cell_of,
-                       hist);
-    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, s, (const GridParams*)gp, (const int*)hist, start,
-                       cursor);
-    hipLaunchKernelGGL(k_scatter, dim3((S + 255) / 256), dim3(256), 0, s, scene, S, (const int*)cell_of, cursor, sorted);
-    hipLaunchKernelGGL(k_cull, dim3((G + 3) / 4), dim3(256), 0, s, frames, G, L, (const GridParams*)gp,
-                       (const int*)start, (const float4*)sorted, mask, Wp);
+    hipLaunchKernelGGL(k_bounds_partial, dim3(nblk), dim3(256), 0, s, scene, S, w.part);
+    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(256), 0, s, (const float*)w.part, nblk, cell_req, w.gp);
+    hipLaunchKernelGGL(k_cell_count, dim3((S + 255) / 256), dim3(256), 0, s, scene, S, (const GridParams*)w.gp,
+                       w.cell_of, w.hist);
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, s, (const GridParams*)w.gp, (const int*)w.hist, w.start,
+                       w.cursor);
+    hipLaunchKernelGGL(k_scatter, dim3((S + 255) / 256), dim3(256), 0, s, scene, S, (const int*)w.cell_of, w.cursor,
+                       w.sorted);
+    hipLaunchKernelGGL(k_cull_count, dim3((G + 3) / 4), dim3(256), 0, s, frames, G, L, (const GridParams*)w.gp,
+                       (const int*)w.start, (const float4*)w.sorted, cnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_crop_emit_grid(const float* scene, int S, const double* frames, int G, const CropLimits& L,
+                                 const void* grid_ws, const int* cnt, const long long* offsets, int* idx,
+                                 long long capacity, double* pts_g, hipStream_t s) {
+    GridWs w((void*)grid_ws, S);
+    hipLaunchKernelGGL(k_cull_emit, dim3(G), dim3(256), 0, s, scene, S, frames, G, L,
+                       (const GridParams*)w.gp, (const int*)w.start, (const float4*)w.sorted, cnt, offsets, idx,
+                       capacity, pts_g);
     return hipGetLastError();
 }
 

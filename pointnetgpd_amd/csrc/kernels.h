@@ -67,15 +67,21 @@ constexpr int GRID_MAX_DIM = 64;
 constexpr int GRID_CELLS = GRID_MAX_DIM * GRID_MAX_DIM * GRID_MAX_DIM;
 struct GridParams { double origin[3]; double inv_cell; int dim[3]; int pad; };
 size_t crop_grid_bytes(int S);
-hipError_t launch_crop_mask_grid(const float* scene, int S, const double* frames, int G, const CropLimits& L,
-                                 unsigned long long* mask, int Wp, void* grid_ws, hipStream_t s);
+hipError_t launch_crop_count_grid(const float* scene, int S, const double* frames, int G, const CropLimits& L,
+                                  void* grid_ws, int* cnt, hipStream_t s);
+hipError_t launch_crop_emit_grid(const float* scene, int S, const double* frames, int G, const CropLimits& L,
+                                 const void* grid_ws, const int* cnt, const long long* offsets, int* idx,
+                                 long long capacity, double* pts_g, hipStream_t s);
 
+// PNGPD_CROP_BRUTE=1 in the environment selects the all-pairs pass with its [G, S/64] bit mask (the tests
+// cross-check the culled pass against it); the mask is part of the workspace only then.
+bool crop_brute_mode();
 hipError_t launch_crop_count(const float* scene, int S, const double* grasps, int G, const CropLimits& L,
                              double* frames, unsigned long long* mask, void* grid_ws, int* cnt,
                              long long* offsets, hipStream_t s, bool frames_given = false);
-hipError_t launch_crop_emit(const float* scene, int S, int G, const double* frames,
-                            const unsigned long long* mask, const long long* offsets, int* idx,
-                            long long capacity, double* pts_g, hipStream_t s);
+hipError_t launch_crop_emit(const float* scene, int S, int G, const CropLimits& L, const double* frames,
+                            const unsigned long long* mask, const void* grid_ws, const int* cnt,
+                            const long long* offsets, int* idx, long long capacity, double* pts_g, hipStream_t s);
 hipError_t launch_crop_gather(const float* scene, const double* frames, const int* idx, const long long* offsets,
                               const int* cnt, int G, int R, int P, int min_points, const int* sel,
                               unsigned long long seed, int first_grasp_id, float* pts_out, int* sel_out,

@@ -101,8 +101,8 @@ def collect_pc_frames(frames, pc, limits, return_points=True) -> CropResult:
         total = int(offsets[G].item())
         indices = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
         points_g = torch.empty((max(total, 1), 3), dtype=torch.float64, device=dev) if return_points else None
-        _lib.check(lib.pngpd_crop_emit(_ptr(scene), S, G, _ptr(ws), nbytes, _ptr(offsets), _ptr(indices), total,
-                                       _ptr(points_g), stream))
+        _lib.check(lib.pngpd_crop_emit(_ptr(scene), S, G, lim, _ptr(ws), nbytes, _ptr(counts), _ptr(offsets),
+                                       _ptr(indices), total, _ptr(points_g), stream))
     return CropResult(counts, offsets, indices[:total], points_g[:total] if return_points else None, scene, ws, G)
 
 

@@ -209,10 +209,11 @@ def test_online_pipeline_ranks_good_grasps():
     assert torch.equal(pts_slice, pts_all[30:60])
 
 
-@pytest.mark.parametrize("S,G,cube", [(300_000, 200, 0.4), (5_000, 50, 0.05), (2_000, 10, 3.0)])
+@pytest.mark.parametrize("S,G,cube", [(300_000, 200, 0.4), (5_000, 50, 0.05), (2_000, 10, 3.0), (90_000, 12, 0.05)])
 def test_grid_culled_pass_equals_all_pairs_pass(S, G, cube, monkeypatch):
     """The spatially culled mask pass and the brute-force all-pairs pass give identical crops
-    (dense scene, a scene smaller than one gripper, and a sparse scene much larger than the grid)."""
+    (dense scene, a scene smaller than one gripper, a sparse scene much larger than the grid, and a scene so
+    dense that a gripper holds more points than a wave sorts in LDS: the index-slab path)."""
     seed = 97 + G
     scene = torch.from_numpy(synth.scene_points(seed, S, cube)).cuda()
     grasps = synth.random_grasps(seed, G, cube, min(0.03, cube / 4))
@@ -236,3 +237,7 @@ def test_grid_culling_with_degenerate_scenes():
     res = hc.collect_pc(g, torch.from_numpy(pts).cuda(), LIMITS)
     np.testing.assert_array_equal(res.counts.cpu().numpy(), [500, 0])
     np.testing.assert_array_equal(res.indices.cpu().numpy(), np.arange(500))
+    pts = np.tile(np.array([[0.1, 0.1, 0.1]], dtype=np.float32), (140_000, 1))     # one cell, two index slabs
+    res = hc.collect_pc(g, torch.from_numpy(pts).cuda(), LIMITS)
+    np.testing.assert_array_equal(res.counts.cpu().numpy(), [140_000, 0])
+    np.testing.assert_array_equal(res.indices.cpu().numpy(), np.arange(140_000))
