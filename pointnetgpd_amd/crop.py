@@ -148,27 +148,38 @@ def _mix64(z):
         return z ^ (z >> np.uint64(31))
 
 
+def _mix32(x):
+    with np.errstate(over="ignore"):
+        x = np.asarray(x, dtype=np.uint32)
+        x = x ^ (x >> np.uint32(15))
+        x = x * np.uint32(0x2C1B3C6D)
+        x = x ^ (x >> np.uint32(12))
+        x = x * np.uint32(0x297A2D39)
+        return x ^ (x >> np.uint32(15))
+
+
 def draw_selection(seed: int, g: int, r: int, n: int, P: int, replace_when_equal: bool = False) -> np.ndarray:
     """The P positions the device draws for (grasp g, repeat r) when the grasp holds n points.
     replace_when_equal: the dataset's rule (n == P drawn with replacement, model/dataset.py:1104)."""
     with np.errstate(over="ignore"):
         inner = _mix64((np.uint64(g) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(r)) & _M)
         key = _mix64(np.uint64(seed & (2 ** 64 - 1)) ^ inner)
-        i = np.arange(P, dtype=np.uint64)
         if n < P + int(replace_when_equal):
+            i = np.arange(P, dtype=np.uint64)
             u = _mix64((key + i) & _M) >> np.uint64(32)
             return ((u * np.uint64(n)) >> np.uint64(32)).astype(np.int32)
         hb = 1
         while (1 << (2 * hb)) < n:
             hb += 1
-        m = np.uint64((1 << hb) - 1)
-        x = i.copy()
+        m = np.uint32((1 << hb) - 1)
+        rk = [np.uint32(int(_mix64((key + (np.uint64(t + 1) << np.uint64(32))) & _M)) >> 32) for t in range(4)]
+        x = np.arange(P, dtype=np.uint32)
         todo = np.ones(P, dtype=bool)
         while todo.any():
-            L, Rh = x[todo] >> np.uint64(hb), x[todo] & m
+            L, Rh = x[todo] >> np.uint32(hb), x[todo] & m
             for t in range(4):
-                F = (_mix64((key + (np.uint64(t + 1) << np.uint64(32)) + Rh) & _M) >> np.uint64(20)) & m
+                F = _mix32(Rh ^ rk[t]) & m
                 L, Rh = Rh, L ^ F
-            x[todo] = (L << np.uint64(hb)) | Rh
-            todo = x >= np.uint64(n)
+            x[todo] = (L << np.uint32(hb)) | Rh
+            todo = x >= np.uint32(n)
         return x.astype(np.int32)

@@ -171,35 +171,65 @@ __host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long 
     return z ^ (z >> 31);
 }
 
-// i-th draw for (grasp g, repeat r) out of n cropped points, P draws in total.
+// Draws for (grasp g, repeat r) out of n cropped points, P draws in total.
 // n >= P: i -> a keyed 4-round Feistel permutation of [0, 4^hb) cycle-walked into [0, n): the P
 //         draws are distinct (sampling without replacement);  n < P: independent uniform draws.
 // replace_when_equal: n == P is drawn WITH replacement (the dataset's `len > N` rule,
 // model/dataset.py:1104-1111) instead of without (the online `len >= N` rule, apps/kinect2grasp.py:756).
-__host__ __device__ __forceinline__ int draw_selection(unsigned long long seed, int g, int r, int i, int n, int P,
-                                                       int replace_when_equal = 0) {
-    const unsigned long long key = mix64(seed ^ mix64((unsigned long long)g * 0x9E3779B97F4A7C15ull + (unsigned long long)r));
-    if (n < P + replace_when_equal) {
-        const unsigned long long u = mix64(key + (unsigned long long)i) >> 32;
-        return (int)((u * (unsigned long long)n) >> 32);
-    }
-    int hb = 1;
-    while ((1ll << (2 * hb)) < (long long)n) ++hb;
-    const unsigned long long m = (1ull << hb) - 1;
-    unsigned long long x = (unsigned long long)i;
-    do {
-        unsigned long long Lh = x >> hb, Rh = x & m;
-        for (int t = 0; t < 4; ++t) {
-            const unsigned long long F = (mix64(key + ((unsigned long long)(t + 1) << 32) + Rh) >> 20) & m;
-            const unsigned long long nl = Rh;
-            Rh = Lh ^ F;
-            Lh = nl;
-        }
-        x = (Lh << hb) | Rh;
-    } while (x >= (unsigned long long)n);
-    return (int)x;
+// The per-(g, r) part (key, four 32-bit round keys) is set up once; a draw then costs 32-bit arithmetic only
+// (the round function is a 2-multiply 32-bit mixer): the gather kernel is bound by this arithmetic.
+__host__ __device__ __forceinline__ unsigned int mix32(unsigned int x) {
+    x ^= x >> 15;
+    x *= 0x2c1b3c6du;
+    x ^= x >> 12;
+    x *= 0x297a2d39u;
+    x ^= x >> 15;
+    return x;
 }
 
+struct Selector {
+    unsigned long long key;
+    unsigned int rk[4], m;
+    int n, hb;
+    bool with_replacement;
+
+    __host__ __device__ __forceinline__ void init(unsigned long long seed, int g, int r, int n_, int P,
+                                                  int replace_when_equal) {
+        key = mix64(seed ^ mix64((unsigned long long)g * 0x9E3779B97F4A7C15ull + (unsigned long long)r));
+        n = n_;
+        with_replacement = n < P + replace_when_equal;
+        hb = 1;
+        while ((1ll << (2 * hb)) < (long long)n) ++hb;
+        m = (1u << hb) - 1u;
+        for (int t = 0; t < 4; ++t) rk[t] = (unsigned int)(mix64(key + ((unsigned long long)(t + 1) << 32)) >> 32);
+    }
+
+    __host__ __device__ __forceinline__ int draw(int i) const {
+        if (with_replacement) {
+            const unsigned long long u = mix64(key + (unsigned long long)i) >> 32;
+            return (int)((u * (unsigned long long)n) >> 32);
+        }
+        unsigned int x = (unsigned int)i;
+        do {
+            unsigned int Lh = x >> hb, Rh = x & m;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const unsigned int F = mix32(Rh ^ rk[t]) & m;
+                const unsigned int nl = Rh;
+                Rh = Lh ^ F;
+                Lh = nl;
+            }
+            x = (Lh << hb) | Rh;
+        } while (x >= (unsigned int)n);
+        return (int)x;
+    }
+};
+
+constexpr int GATHER_LDS_POINTS = 2048;      // points of one grasp held in LDS by the gather kernel
+
+// One workgroup per grasp, all its repeats.  The grasp's points are transformed to the gripper frame once,
+// rounded to float32 and kept in LDS; the R x P draws then read LDS.  (Drawing straight from the scene costs a
+// 64-byte sector per 12-byte point, R times over; a grasp with more than GATHER_LDS_POINTS points does that.)
 __global__ __launch_bounds__(256) void crop_gather_kernel(const float* __restrict__ scene,
                                                           const double* __restrict__ frames,
                                                           const int* __restrict__ idx,
@@ -211,33 +241,60 @@ __global__ __launch_bounds__(256) void crop_gather_kernel(const float* __restric
                                                           int* __restrict__ sel_out,
                                                           unsigned char* __restrict__ valid,
                                                           int replace_when_equal, int channels_first) {
-    const int g = blockIdx.x / R, r = blockIdx.x % R, tid = threadIdx.x;
+    __shared__ float s_pts[GATHER_LDS_POINTS * 3];
+    const int g = blockIdx.x, tid = threadIdx.x;
     const int n = cnt[g];
-    float* out = pts_out + (size_t)blockIdx.x * P * 3;
     if (n < min_points) {     // apps/kinect2grasp.py:746-751: scored 0 without running the network
-        for (int i = tid; i < P * 3; i += 256) out[i] = 0.f;
+        float* out = pts_out + (size_t)g * R * P * 3;
+        for (int i = tid; i < R * P * 3; i += 256) out[i] = 0.f;
         if (sel_out != nullptr)
-            for (int i = tid; i < P; i += 256) sel_out[(size_t)blockIdx.x * P + i] = -1;
-        if (r == 0 && tid == 0) valid[g] = 0;
+            for (int i = tid; i < R * P; i += 256) sel_out[(size_t)g * R * P + i] = -1;
+        if (tid == 0) valid[g] = 0;
         return;
     }
-    if (r == 0 && tid == 0) valid[g] = 1;
+    if (tid == 0) valid[g] = 1;
     const double* f = frames + (size_t)g * 12;
     const long long base = offsets[g];
-    for (int i = tid; i < P; i += 256) {
-        const int j = sel != nullptr ? sel[(size_t)blockIdx.x * P + i] : draw_selection(seed, first_grasp_id + g, r, i, n, P, replace_when_equal);
-        if (sel_out != nullptr) sel_out[(size_t)blockIdx.x * P + i] = j;
-        const int s = idx[base + j];
-        const float* p = scene + (size_t)s * 3;
-        const PointD q = to_gripper(f, (double)p[0], (double)p[1], (double)p[2]);
-        if (channels_first) {        // [3,P]: grasp_pc[...].T of the dataset (model/dataset.py:1106)
-            out[i] = (float)q.x;
-            out[P + i] = (float)q.y;
-            out[2 * P + i] = (float)q.z;
-        } else {
-            out[3 * i + 0] = (float)q.x;
-            out[3 * i + 1] = (float)q.y;
-            out[3 * i + 2] = (float)q.z;
+    const bool in_lds = n <= GATHER_LDS_POINTS;
+    if (in_lds) {
+        for (int i = tid; i < n; i += 256) {
+            const float* p = scene + (size_t)idx[base + i] * 3;
+            const PointD q = to_gripper(f, (double)p[0], (double)p[1], (double)p[2]);
+            s_pts[3 * i + 0] = (float)q.x;
+            s_pts[3 * i + 1] = (float)q.y;
+            s_pts[3 * i + 2] = (float)q.z;
+        }
+        __syncthreads();
+    }
+    for (int r = 0; r < R; ++r) {
+        const size_t row = (size_t)g * R + r;
+        float* out = pts_out + row * P * 3;
+        Selector pick;
+        pick.init(seed, first_grasp_id + g, r, n, P, replace_when_equal);
+        for (int i = tid; i < P; i += 256) {
+            const int j = sel != nullptr ? sel[row * P + i] : pick.draw(i);
+            if (sel_out != nullptr) sel_out[row * P + i] = j;
+            float x, y, z;
+            if (in_lds) {
+                x = s_pts[3 * j + 0];
+                y = s_pts[3 * j + 1];
+                z = s_pts[3 * j + 2];
+            } else {
+                const float* p = scene + (size_t)idx[base + j] * 3;
+                const PointD q = to_gripper(f, (double)p[0], (double)p[1], (double)p[2]);
+                x = (float)q.x;
+                y = (float)q.y;
+                z = (float)q.z;
+            }
+            if (channels_first) {        // [3,P]: grasp_pc[...].T of the dataset (model/dataset.py:1106)
+                out[i] = x;
+                out[P + i] = y;
+                out[2 * P + i] = z;
+            } else {
+                out[3 * i + 0] = x;
+                out[3 * i + 1] = y;
+                out[3 * i + 2] = z;
+            }
         }
     }
 }
@@ -323,8 +380,8 @@ hipError_t launch_crop_gather(const float* scene, const double* frames, const in
                               unsigned char* valid, hipStream_t s, int replace_when_equal, int channels_first) {
     if (!scene || !frames || !idx || !offsets || !cnt || !pts_out || !valid || G < 1 || R < 1 || P < 1)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(crop_gather_kernel, dim3(G * R), dim3(256), 0, s, scene, frames, idx, offsets, cnt, R, P,
-                       min_points, sel, seed, first_grasp_id, pts_out, sel_out, valid, replace_when_equal, channels_first);
+    hipLaunchKernelGGL(crop_gather_kernel, dim3(G), dim3(256), 0, s, scene, frames, idx, offsets, cnt, R, P, min_points,
+                       sel, seed, first_grasp_id, pts_out, sel_out, valid, replace_when_equal, channels_first);
     return hipGetLastError();
 }
 
