@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void k_cull_emit(const float* __restrict__ sce
                 int at = 0;
                 if (lane == 0) at = atomicAdd(&s_fill, __popcll(bal));
                 at = __shfl(at, 0);
-                if (hit) list[at + __popcll(bal & below)] = s;
+                const int pos = at + (int)__popcll(bal & below);
+                if (hit && pos < CULL_CAP) list[pos] = s;      // pos < n <= CULL_CAP when cnt is this scene's count
             }
         }
         __syncthreads();
