@@ -292,6 +292,113 @@ __global__ __launch_bounds__(256) void fc_bf16x3_kernel(const float* __restrict_
     }
 }
 
+// Small-batch variant (a few thousand rows): 32 rows x 128 columns per workgroup, K in blocks of 64.
+// With 32-row tiles every wave owns its 32 columns, so the weight fragments - already in fragment order in
+// memory - go straight from global memory to registers, three k-blocks ahead; only the activations (shared by the
+// four waves, split into hi/lo planes while staged) pass through LDS.  One barrier per 12 MFMAs of a wave
+// instead of per 6, no LDS traffic for the weights, all 256 threads stage activations.
+constexpr int X3D_BK = 64;
+
+__global__ __launch_bounds__(256) void fc_bf16x3_direct_kernel(const float* __restrict__ X,
+                                                               const char* __restrict__ Wp,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ Y, int M, int N, int K, int relu) {
+    constexpr int STAGE = 4 * 2 * 1024;               // [ks4][plane2] fragments of 1 KiB
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * X3_BN;
+    const int nkb = K / X3D_BK, ksteps = K / 16;
+
+    // A staging: thread -> (row 0..31, k-group g 0..7 of 8 floats); slot XOR-swizzled as in the kernel above
+    const int arow = tid >> 3, ag = tid & 7;
+    const int a_ks = ag >> 1, a_h = ag & 1;
+    const int a_off = (a_ks * 2) * 1024 + (32 * a_h + (arow ^ ag)) * 16;     // hi plane; lo plane + 1024
+    const bool a_ok = (m0 + arow) < M;
+    const float* a_src = X + (size_t)(a_ok ? m0 + arow : 0) * K + ag * 8;
+    const char* b_src = Wp + ((size_t)(n0 / 32 + wave) * ksteps * 2) * 1024 + lane * 16;
+
+    auto load_a = [&](int kb, float4& v0, float4& v1) {
+        if (a_ok) {
+            v0 = *(const float4*)(a_src + kb * X3D_BK);
+            v1 = *(const float4*)(a_src + kb * X3D_BK + 4);
+        } else {
+            v0 = v1 = make_float4(0, 0, 0, 0);
+        }
+    };
+    auto store_a = [&](const float4& v0, const float4& v1, char* stage) {
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        bf16x8_t hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hi[j] = (__bf16)x[j];
+            lo[j] = (__bf16)(x[j] - (float)hi[j]);
+        }
+        *(bf16x8_t*)(stage + a_off) = hi;
+        *(bf16x8_t*)(stage + a_off + 1024) = lo;
+    };
+    auto load_b = [&](int kb, bf16x8_t (&b)[4][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) b[ks][pl] = *(const bf16x8_t*)(b_src + ((size_t)(kb * 4 + ks) * 2 + pl) * 1024);
+    };
+    // one accumulator, k-steps in order, the three products in the order of the kernel above: the two kernels
+    // give bit-identical results, so an output does not depend on which one the batch size selected
+    f32x16 acc = f32x16{0};
+    auto compute = [&](const char* cur, const bf16x8_t (&b)[4][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int g = 2 * ks + h;
+            const char* pa = cur + (ks * 2) * 1024 + (32 * h + (r ^ g)) * 16;
+            const bf16x8_t ah = *(const bf16x8_t*)pa;
+            const bf16x8_t al = *(const bf16x8_t*)(pa + 1024);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[ks][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[ks][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[ks][0], acc, 0, 0, 0);
+        }
+    };
+
+    // Loads run three k-blocks ahead of the MFMAs (register rings of four slots) and the barriers order LDS only,
+    // so they stay in flight across them.  What bounds the layer at a few thousand rows is the L2 traffic of
+    // re-reading the weights once per 32-row workgroup (268 MB for 4096 x 1024 -> 512, ~10 TB/s measured).
+    bf16x8_t b[4][4][2];
+    float4 va[4][2];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+        if (u < nkb) {
+            load_a(u, va[u][0], va[u][1]);
+            load_b(u, b[u]);
+        }
+    store_a(va[0][0], va[0][1], smem);
+    lds_barrier();
+    for (int kb0 = 0; kb0 < nkb; kb0 += 4) {           // nkb is a multiple of 4: slots are compile-time constants
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kb = kb0 + u;
+            const int nx = (u + 3) & 3;
+            if (kb + 3 < nkb) {
+                load_a(kb + 3, va[nx][0], va[nx][1]);
+                load_b(kb + 3, b[nx]);
+            }
+            compute(smem + (u & 1) * STAGE, b[u]);
+            if (kb + 1 < nkb) store_a(va[(u + 1) & 3][0], va[(u + 1) & 3][1], smem + ((u + 1) & 1) * STAGE);
+            lds_barrier();
+        }
+    }
+    const int col = n0 + wave * 32 + r;
+    const float bv = bias[col];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (row < M) {
+            float v = acc[i] + bv;
+            if (relu) v = __builtin_fmaxf(v, 0.f);
+            Y[(size_t)row * N + col] = v;
+        }
+    }
+}
+
 hipError_t launch_fc_bf16x3(const float* X, const void* Wp, const float* b, float* Y, int M, int N, int K, int relu,
                             hipStream_t s) {
     if (!X || !Wp || !b || !Y || M < 1 || N % X3_BN != 0 || K % X3_BK != 0) return hipErrorInvalidValue;
@@ -299,6 +406,9 @@ hipError_t launch_fc_bf16x3(const float* X, const void* Wp, const float* b, floa
     if (wg64 >= 1024) {      // at least ~4 workgroups per CU with 64-row tiles
         dim3 grid(N / X3_BN, (M + 63) / 64);
         hipLaunchKernelGGL(fc_bf16x3_kernel<64>, grid, dim3(256), 0, s, X, (const char*)Wp, b, Y, M, N, K, relu);
+    } else if (K % (4 * X3D_BK) == 0) {
+        dim3 grid(N / X3_BN, (M + 31) / 32);
+        hipLaunchKernelGGL(fc_bf16x3_direct_kernel, grid, dim3(256), 0, s, X, (const char*)Wp, b, Y, M, N, K, relu);
     } else {
         dim3 grid(N / X3_BN, (M + 31) / 32);
         hipLaunchKernelGGL(fc_bf16x3_kernel<32>, grid, dim3(256), 0, s, X, (const char*)Wp, b, Y, M, N, K, relu);

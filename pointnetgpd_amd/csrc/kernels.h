@@ -6,6 +6,14 @@
 
 namespace pngpd {
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also fences global memory, i.e. waits for every
+// global load still in flight - which drains a register prefetch pipeline at each barrier.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 constexpr int C1 = 64;     // conv1 output channels
 constexpr int C2 = 128;    // conv2 output channels
 constexpr int C3 = 1024;   // conv3 output channels
