@@ -461,7 +461,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
             }
             rm[7] = max3(rm[7], max3(carry[0], carry[1], carry[2]), carry[3]);
             STAMP(g, 3);
-            __syncthreads();
+            lds_barrier();          // orders the A-fragment buffers only: the point loads of the next produce step stay in flight
             STAMP(g, 4);
 #ifdef PNGPD_STAMPS
             ++g;
