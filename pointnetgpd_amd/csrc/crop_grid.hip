@@ -274,11 +274,91 @@ __device__ __forceinline__ void block_sort(int* list, int n, int tid) {
     }
 }
 
+// Ascending sort of n scene indices held in LDS, result in `out`: the indices of one grasp are spread roughly
+// evenly between their minimum and maximum, so 256 equal index ranges hold a handful each - histogram, scan,
+// scatter, and every thread orders one bucket by insertion.  A bucket of more than 64 (clustered indices) falls
+// back to the bitonic network.  Five barriers instead of fifty-five.
+__device__ __forceinline__ const int* block_bucket_sort(int* list, int* out, int* s_small, int n, int tid) {
+    // s_small: 256 counts | 257 starts | 256 cursors | 8 scratch
+    int* hist = s_small;
+    int* start = s_small + 256;
+    int* cursor = s_small + 513;
+    int* red = s_small + 769;
+    const int lane = tid & 63, wave = tid >> 6;
+    int mn = 0x7fffffff, mx = 0;
+    for (int i = tid; i < n; i += 256) {
+        const int v = list[i];
+        mn = min(mn, v);
+        mx = max(mx, v);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mn = min(mn, __shfl_xor(mn, off));
+        mx = max(mx, __shfl_xor(mx, off));
+    }
+    if (lane == 0) {
+        red[wave] = mn;
+        red[4 + wave] = mx;
+    }
+    hist[tid] = 0;
+    __syncthreads();
+    mn = min(min(red[0], red[1]), min(red[2], red[3]));
+    mx = max(max(red[4], red[5]), max(red[6], red[7]));
+    int sh = 0;
+    while (((mx - mn) >> sh) > 255) ++sh;
+    for (int i = tid; i < n; i += 256) atomicAdd(&hist[(list[i] - mn) >> sh], 1);
+    __syncthreads();
+    if (wave == 0) {                                   // exclusive scan of 256 counts: 4 per lane
+        const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+        const int sum = c0 + c1 + c2 + c3;
+        int inc = sum, big = max(max(c0, c1), max(c2, c3));
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) big = max(big, __shfl_xor(big, off));
+        int run = inc - sum;
+        start[4 * lane] = run;     cursor[4 * lane] = run;     run += c0;
+        start[4 * lane + 1] = run; cursor[4 * lane + 1] = run; run += c1;
+        start[4 * lane + 2] = run; cursor[4 * lane + 2] = run; run += c2;
+        start[4 * lane + 3] = run; cursor[4 * lane + 3] = run; run += c3;
+        if (lane == 63) start[256] = run;
+        if (lane == 0) red[0] = big;
+    }
+    __syncthreads();
+    if (red[0] > 64) {
+        block_sort(list, n, tid);
+        return list;
+    }
+    for (int i = tid; i < n; i += 256) {
+        const int v = list[i];
+        out[atomicAdd(&cursor[(v - mn) >> sh], 1)] = v;
+    }
+    __syncthreads();
+    {
+        const int b0 = start[tid], b1 = start[tid + 1];
+        for (int i = b0 + 1; i < b1; ++i) {
+            const int v = out[i];
+            int j = i - 1;
+            while (j >= b0 && out[j] > v) {
+                out[j + 1] = out[j];
+                --j;
+            }
+            out[j + 1] = v;
+        }
+    }
+    __syncthreads();
+    return out;
+}
+
 constexpr int CULL_CAP = 4096;               // hits a workgroup sorts in LDS; also the words of its fallback bitmap
 
 // idx[offsets[g] ..] = ascending scene indices of the points inside the gripper region, pts_g = the same points
 // in the gripper frame (float64).  One workgroup per grasp; its four waves share the rows of cells.  Up to
-// CULL_CAP hits are collected in LDS in the order they are found and sorted there; a grasp with more goes over
+// CULL_CAP hits are collected in LDS in the order they are found and sorted there (block_bucket_sort); a grasp
+// with more goes over
 // the scene's index range in slabs of 32*CULL_CAP indices, marks the hits of a slab in an LDS bitmap and expands
 // it - ascending by construction.
 __global__ __launch_bounds__(256) void k_cull_emit(const float* __restrict__ scene, int S,
@@ -288,6 +368,7 @@ __global__ __launch_bounds__(256) void k_cull_emit(const float* __restrict__ sce
                                                    const long long* __restrict__ offsets, int* __restrict__ idx,
                                                    long long capacity, double* __restrict__ pts_g) {
     __shared__ int list[CULL_CAP];
+    __shared__ int s_small[800];
     __shared__ int s_fill;
     __shared__ int s_scan[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -335,8 +416,13 @@ __global__ __launch_bounds__(256) void k_cull_emit(const float* __restrict__ sce
             }
         }
         __syncthreads();
-        block_sort(list, n, tid);
-        for (int i = tid; i < n; i += 256) write_out(base + i, list[i]);
+        // up to half the capacity the upper half of the list is the bucket sort's output; beyond, sort in place
+        const int* ordered = list;
+        if (n <= CULL_CAP / 2)
+            ordered = block_bucket_sort(list, list + CULL_CAP / 2, s_small, n, tid);
+        else
+            block_sort(list, n, tid);
+        for (int i = tid; i < n; i += 256) write_out(base + i, ordered[i]);
         return;
     }
     long long o = base;

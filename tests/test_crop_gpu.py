@@ -237,6 +237,18 @@ def test_grid_culling_with_degenerate_scenes():
     res = hc.collect_pc(g, torch.from_numpy(pts).cuda(), LIMITS)
     np.testing.assert_array_equal(res.counts.cpu().numpy(), [500, 0])
     np.testing.assert_array_equal(res.indices.cpu().numpy(), np.arange(500))
+    # 3000 hits: above half the LDS list capacity (sorted in place by the bitonic network)
+    pts = np.tile(np.array([[0.1, 0.1, 0.1]], dtype=np.float32), (3000, 1))
+    res = hc.collect_pc(g, torch.from_numpy(pts).cuda(), LIMITS)
+    np.testing.assert_array_equal(res.indices.cpu().numpy(), np.arange(3000))
+    # clustered indices: 150 hits at the front and one at the far end of a large scene put more than 64 hits
+    # into one bucket of the bucket sort (its fallback path)
+    pts = np.full((300_000, 3), 2.0, dtype=np.float32)
+    pts[:150] = [0.1, 0.1, 0.1]
+    pts[-1] = [0.1, 0.1, 0.1]
+    res = hc.collect_pc(g, torch.from_numpy(pts).cuda(), LIMITS)
+    np.testing.assert_array_equal(res.counts.cpu().numpy(), [151, 0])
+    np.testing.assert_array_equal(res.indices.cpu().numpy(), np.r_[np.arange(150), 299_999])
     pts = np.tile(np.array([[0.1, 0.1, 0.1]], dtype=np.float32), (140_000, 1))     # one cell, two index slabs
     res = hc.collect_pc(g, torch.from_numpy(pts).cuda(), LIMITS)
     np.testing.assert_array_equal(res.counts.cpu().numpy(), [140_000, 0])
