@@ -77,6 +77,65 @@ def cpu_baseline(P, k, seed, seconds_budget=15.0):
                       f"torch {torch.__version__} CPU"}
 
 
+def cpu_baseline_train(P, k, seconds_budget=15.0):
+    """Oracle training step (eager fp32 PyTorch: forward, nll_loss, backward, Adam) on the host CPU."""
+    from oracle import pointnet_oracle as po
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    Bc = 64
+    m = po.build_cls(P, k, synth.torch_state_dict(0, k, 0.02, 1.0), eval_mode=False)
+    opt = torch.optim.Adam(m.parameters(), lr=0.005)
+    x = torch.from_numpy(synth.candidate_points(0, Bc, P, "gripper"))
+    target = torch.from_numpy((synth.uniform(0, "bench/labels", (Bc,)) < 0.5).astype("int64"))
+
+    def one():
+        opt.zero_grad()
+        out, _ = m(x)
+        torch.nn.functional.nll_loss(out, target).backward()
+        opt.step()
+
+    one()
+    t0 = time.perf_counter()
+    one()
+    dt1 = time.perf_counter() - t0
+    iters = int(max(2, min(20, seconds_budget / max(dt1, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": round(Bc * iters / dt, 2), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"oracle PointNetCls({P},3,{k}).train(): {iters} steps of batch {Bc} (forward, nll_loss, backward, "
+                      f"Adam), torch {torch.__version__} CPU"}
+
+
+def cpu_baseline_online(scene, grasps, limits, P, k, R, n_grasps=200):
+    """The reference's online loop on the host CPU for the first `n_grasps` grasps: numpy float64 crop over the
+    whole scene per grasp, then R draws of P points scored one candidate at a time (batch 1)."""
+    import numpy as np
+    from oracle import crop_oracle as co
+    from oracle import pointnet_oracle as po
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    m = po.build_cls(P, k, synth.torch_state_dict(0, k, 0.02))
+    rng = np.random.RandomState(0)
+    t0 = time.perf_counter()
+    idx, pts = co.crop_numpy(grasps[:n_grasps], scene, limits)
+    t_crop = time.perf_counter() - t0
+    scored = 0
+    t0 = time.perf_counter()
+    for pg in pts:
+        if len(pg) < 20:
+            continue
+        for _ in range(R):
+            sel = rng.choice(len(pg), P, replace=len(pg) < P)
+            po.oracle_test_network(m, pg[sel])
+        scored += 1
+    t_score = time.perf_counter() - t0
+    return {"value": round(n_grasps / (t_crop + t_score), 3), "unit": "grasps/s", "cores": threads, "kind": "port",
+            "sample": f"first {n_grasps} grasps on the full {len(scene)}-point scene: numpy crop {t_crop:.2f} s + "
+                      f"{scored}x{R} batch-1 oracle forwards {t_score:.2f} s, torch {torch.__version__} CPU"}
+
+
 def online_workload(args, dev, rank, n_gpus, dist):
     """Config 5: 1M-point scene x 10k grasps per GPU: crop + subsample (3 repeats) + scoring + vote."""
     from pointnetgpd_amd import crop as hc
@@ -124,7 +183,8 @@ def online_workload(args, dev, rank, n_gpus, dist):
     total_idx = int(res.offsets[-1].item())
     crop_bytes = S * 12 + G * 15 * 8 + G * 4 + total_idx * 4            # algorithmic: scene once, frames, counts, indices
     if rank == 0:
-        print(json.dumps({
+        crop_gbps = crop_bytes / (crop_ms * 1e-3) / 1e9
+        line = {
             "metric": "grasps scored/sec, online crop + scoring", "value": round(n_gpus * G * args.steps / elapsed, 1),
             "unit": "grasps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -133,7 +193,16 @@ def online_workload(args, dev, rank, n_gpus, dist):
                        "crop_ms": round(crop_ms, 3), "score_ms": round(score_ms, 3), "pair_tests_per_s": round(S * G / (crop_ms * 1e-3), 1),
                        "crop_algorithmic_GBps": round(crop_bytes / (crop_ms * 1e-3) / 1e9, 2),
                        "mean_points_per_grasp": round(total_idx / G, 1), "good_grasps": int(out.order.numel())},
-        }), flush=True)
+            # the crop stage against the HBM roofline (its traversal is latency-bound: the algorithmic bytes are
+            # small); the stage that dominates the frame is the scoring, whose kernel the score workload reports
+            "roofline": {"bound": "hbm", "kernel": "crop count + emit (all kernels of collect_pc)",
+                         "achieved": round(crop_gbps, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(crop_gbps / 8000.0, 5), "traffic": None, "stage_ms": round(crop_ms, 3),
+                         "bytes_per_frame": crop_bytes},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_online(scene.cpu().numpy(), grasps, limits, P, k, R)
+        print(json.dumps(line), flush=True)
 
 
 def train_workload(args, dev, rank, n_gpus, dist):
@@ -164,11 +233,21 @@ def train_workload(args, dev, rank, n_gpus, dist):
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(dist, elapsed, dev)
+    # dominant kernel of the step: the fused conv3 product / max / arg-max kernel, timed with HIP events on the
+    # launch stream inside 20 further full steps (two launches per step)
+    trainer.conv3_ms = []
+    for _ in range(20):
+        trainer.step(x, target)
+    torch.cuda.synchronize(dev)
+    conv3_ms = sum(trainer.conv3_ms) / len(trainer.conv3_ms)
+    trainer.conv3_ms = None
     if rank == 0:
+        conv3_flop = 2.0 * 128 * 1024 * B * P
+        conv3_tf = conv3_flop / (conv3_ms * 1e-3) / 1e12
         # flop of the step as the reference executes it (3 x forward: forward, data and weight gradients); the HIP
         # step does less arithmetic than that (low-rank dense backward of conv3), so this is an equivalent rate
         flop = 3.0 * B * flop_per_candidate(P, k)
-        print(json.dumps({
+        line = {
             "metric": "training samples/sec (fwd+bwd+NLL+Adam)", "value": round(n_gpus * B * args.steps / elapsed, 1),
             "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -176,7 +255,13 @@ def train_workload(args, dev, rank, n_gpus, dist):
             "config": {"workload": f"PointNetCls {k}-class train step, P={P}, batch {B} per GPU, Adam lr 0.005, "
                                    "flat fp32 gradient bucket all-reduced over RCCL",
                        "loss": round(float(loss.item()), 5), "reference_equivalent_tflops": round(flop * args.steps / elapsed / 1e12, 2)},
-        }), flush=True)
+            "roofline": {"bound": "mfma", "kernel": "conv3_pool_train (fp32 MFMA)", "achieved": round(conv3_tf, 2),
+                         "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": round(conv3_tf / PEAK_TFLOPS["fp32"], 4),
+                         "traffic": None, "kernel_ms": round(conv3_ms, 4), "flop_per_launch": conv3_flop},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_train(P, k)
+        print(json.dumps(line), flush=True)
 
 
 def voxel_workload(args, dev, rank, n_gpus, dist):

@@ -290,6 +290,17 @@ int pngpd_forward_infer_timed(const pngpd_model* m, const float* x_dev, int layo
                               void* workspace_dev, size_t workspace_bytes, float* conv_ms_out,
                               void* stream);
 
+/*
+ * Diagnostic: pngpd_train_forward with the fused conv3 product / max / arg-max kernel of each stack bracketed
+ * by HIP events on `stream`; waits for the second one and returns the two kernel durations in milliseconds
+ * (conv3_ms_out[0] = STN, [1] = trunk).  Used by bench.py for the roofline figure of the training step; no
+ * counterpart in the reference.
+ */
+int pngpd_train_forward_timed(int B, int P, int k, const float* x_dev, float* const* params_dev,
+                              int n_slots, float momentum, float* logp_dev, float* trans_dev,
+                              float* feat_dev, void* workspace_dev, size_t workspace_bytes,
+                              float* conv3_ms_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,8 @@ SIGNATURES = {
     "pngpd_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pngpd_train_forward": (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p), c_int, c_float, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pngpd_train_forward_timed": (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p), c_int, c_float, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "pngpd_train_backward": (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pngpd_train_saved": (c_int, [c_int, c_int, c_int, c_void_p, c_size_t, c_int, POINTER(c_void_p), POINTER(c_size_t)]),

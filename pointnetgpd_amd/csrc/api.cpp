@@ -277,6 +277,10 @@ static int forward_impl(const pngpd_model* m, const float* x_dev, int layout, in
         return fail(PNGPD_ERR_STATE, "log-probabilities requested from a model without a head");
     if (feat_dev && !(m->parts & PNGPD_PART_TRUNK))
         return fail(PNGPD_ERR_STATE, "global feature requested from a model without a trunk");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != m->device)
+        return fail(PNGPD_ERR_STATE, "model lives on device %d but device %d is current", m->device, dev);
     hipStream_t s = (hipStream_t)stream;
     Workspace ws(workspace_dev, B);
     auto launch_stack = precision == PNGPD_BF16 ? pngpd::launch_conv_stack_bf16 : pngpd::launch_conv_stack_f32;

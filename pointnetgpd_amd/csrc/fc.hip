@@ -75,55 +75,57 @@ __global__ __launch_bounds__(256) void fc_f32_kernel(const float* __restrict__ X
     }
 }
 
-// One wave per row; lane owns k = 4*lane + 256*c .. +3.  N <= 16 outputs, each a wave reduction.
-__global__ __launch_bounds__(256) void fc_tail_kernel(const float* __restrict__ X,
-                                                      const float* __restrict__ W,
-                                                      const float* __restrict__ bias,
-                                                      float* __restrict__ Y, int M, int N, int K,
-                                                      int tail) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    float out[16];
+// One wave per tile of 16 rows on v_mfma_f32_16x16x4_f32 (A[row = l&15][k = l>>4], B[k = l>>4][col = l&15],
+// D register i = row 4(l>>4) + i, col l&15).  N <= 16 outputs are the 16 columns (the rest zero).  The k order is
+// free as long as A and B agree: lane (r, q = l>>4) owns k = 16j + 4q + e, so both operands come in as float4
+// and W[N, K=256] stays in registers (16 float4 per lane) across the tiles of the wave.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__global__ __launch_bounds__(64) void fc_tail_kernel(const float* __restrict__ X,
+                                                     const float* __restrict__ W,
+                                                     const float* __restrict__ bias,
+                                                     float* __restrict__ Y, int M, int N, int tail) {
+    constexpr int K = FC_TAIL_K;
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    float4 w[K / 16];
 #pragma unroll
-    for (int n = 0; n < 16; ++n) out[n] = 0.f;
-    for (int kc = 0; kc < K; kc += 256) {
-        const float4 x = *(const float4*)(X + (size_t)row * K + kc + 4 * lane);
+    for (int j = 0; j < K / 16; ++j)
+        w[j] = r < N ? *(const float4*)(W + (size_t)r * K + 16 * j + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bv = r < N ? bias[r] : 0.f;
+    const int tiles = (M + 15) / 16;
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        int row = t * 16 + r;
+        row = row < M ? row : M - 1;
+        const float4* xr = (const float4*)(X + (size_t)row * K + 4 * q);
+        float4 x[K / 16];
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
-            if (n < N) {
-                const float4 w = *(const float4*)(W + (size_t)n * K + kc + 4 * lane);
-                out[n] = fmaf(x.x, w.x, fmaf(x.y, w.y, fmaf(x.z, w.z, fmaf(x.w, w.w, out[n]))));
-            }
+        for (int j = 0; j < K / 16; ++j) x[j] = xr[4 * j];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < K / 16; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j].x, w[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j].y, w[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j].z, w[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j].w, w[j].w, acc, 0, 0, 0);
         }
-    }
+        // lane holds rows 4q + i of the tile, column r
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
+        for (int i = 0; i < 4; ++i) {
+            float v = acc[i] + bv;
+            if (tail == FC_TAIL_ADD_IDENTITY) {
+                if (r == 0 || r == 4 || r == 8) v += 1.0f;
+            } else if (tail == FC_TAIL_LOG_SOFTMAX) {
+                float mx = r < N ? v : -INFINITY;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) out[n] += __shfl_xor(out[n], off);
-        if (n < N) out[n] += bias[n];
-    }
-    if (tail == FC_TAIL_ADD_IDENTITY) {
+                for (int off = 8; off >= 1; off >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, off));
+                float sum = r < N ? expf(v - mx) : 0.f;
 #pragma unroll
-        for (int n = 0; n < 16; ++n)
-            if (n == 0 || n == 4 || n == 8) out[n] += 1.0f;
-    } else if (tail == FC_TAIL_LOG_SOFTMAX) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int n = 0; n < 16; ++n)
-            if (n < N) mx = __builtin_fmaxf(mx, out[n]);
-        float sum = 0.f;
-#pragma unroll
-        for (int n = 0; n < 16; ++n)
-            if (n < N) sum += expf(out[n] - mx);
-        const float lse = mx + logf(sum);
-#pragma unroll
-        for (int n = 0; n < 16; ++n) out[n] -= lse;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int n = 0; n < 16; ++n)
-            if (n < N) Y[(size_t)row * N + n] = out[n];
+                for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+                v -= mx + logf(sum);
+            }
+            const int orow = t * 16 + 4 * q + i;
+            if (orow < M && r < N) Y[(size_t)orow * N + r] = v;
+        }
     }
 }
 
@@ -152,8 +154,9 @@ hipError_t launch_fc_f32(const float* X, const float* W, const float* b, float* 
 
 hipError_t launch_fc_tail(const float* X, const float* W, const float* b, float* Y, int M, int N,
                           int K, int tail, hipStream_t s) {
-    if (!X || !W || !b || !Y || M < 1 || N < 1 || N > 16 || K % 256 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fc_tail_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, W, b, Y, M, N, K, tail);
+    if (!X || !W || !b || !Y || M < 1 || N < 1 || N > 16 || K != FC_TAIL_K) return hipErrorInvalidValue;
+    const int tiles = (M + 15) / 16;
+    hipLaunchKernelGGL(fc_tail_kernel, dim3(tiles < 4096 ? tiles : 4096), dim3(64), 0, s, X, W, b, Y, M, N, tail);
     return hipGetLastError();
 }
 

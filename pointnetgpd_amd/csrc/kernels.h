@@ -54,6 +54,7 @@ hipError_t launch_fc_bf16x3(const float* X, const void* Wp, const float* b, floa
                             hipStream_t s);
 
 enum { FC_TAIL_PLAIN = 0, FC_TAIL_ADD_IDENTITY = 1, FC_TAIL_LOG_SOFTMAX = 2 };
+constexpr int FC_TAIL_K = 256;   // input width of the last layer of both FC chains (model/pointnet.py:24, :182)
 // Y[M,N] = tail(X[M,K] * W[N,K]^T + b[N]) for tiny N (<= 16), K % 256 == 0.
 hipError_t launch_fc_tail(const float* X, const float* W, const float* b, float* Y, int M, int N,
                           int K, int tail, hipStream_t s);
@@ -150,6 +151,7 @@ struct Conv3Ws {
     float* gmask;      // [B,1024] pooled gradient after the ReLU mask
     float* G;          // [128,128] W^T diag(q) W
     float* ub;         // [128] constant row of the dense input gradient
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // optional: recorded around the product/max kernel
 };
 hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta, int B,
                        int P, int relu_out, float momentum, double* gram_part, const Conv3Ws& w, float* mean,

@@ -234,9 +234,10 @@ size_t pngpd_train_workspace_bytes(int B, int P, int k) {
     return w.bytes;
 }
 
-int pngpd_train_forward(int B, int P, int k, const float* x_dev, float* const* params_dev, int n_slots,
-                        float momentum, float* logp_dev, float* trans_dev, float* feat_dev, void* workspace_dev,
-                        size_t workspace_bytes, void* stream) {
+// ev: nullptr, or 4 events recorded around the conv3 product/max kernel of the STN (0,1) and the trunk (2,3)
+static int train_forward_impl(int B, int P, int k, const float* x_dev, float* const* params_dev, int n_slots,
+                              float momentum, float* logp_dev, float* trans_dev, float* feat_dev, void* workspace_dev,
+                              size_t workspace_bytes, void* stream, hipEvent_t* ev) {
     if (!x_dev || !params_dev || !logp_dev) return fail(PNGPD_ERR_INVALID, "pngpd_train_forward: NULL argument");
     if (n_slots != PNGPD_SLOTS) return fail(PNGPD_ERR_INVALID, "training table must have %d slots", PNGPD_SLOTS);
     int rc = check_shape(B, P, k, workspace_dev, workspace_bytes);
@@ -244,6 +245,12 @@ int pngpd_train_forward(int B, int P, int k, const float* x_dev, float* const* p
     if ((rc = check_tables(params_dev, true))) return rc;
     hipStream_t s = (hipStream_t)stream;
     TrainWs W(workspace_dev, B, P, k);
+    if (ev) {
+        W.stn.c3.ev_begin = ev[0];
+        W.stn.c3.ev_end = ev[1];
+        W.trunk.c3.ev_begin = ev[2];
+        W.trunk.c3.ev_end = ev[3];
+    }
     float* trans = trans_dev ? trans_dev : W.trans;
     if ((rc = fwd_stack(W.stn, params_dev, PNGPD_U_STN_CONV1, x_dev, nullptr, B, P, 1, momentum, W.part, W.gram_part, s)))
         return rc;
@@ -259,6 +266,37 @@ int pngpd_train_forward(int B, int P, int k, const float* x_dev, float* const* p
     if (feat_dev)
         HIP_TRY(hipMemcpyAsync(feat_dev, W.trunk.pooled, (size_t)B * C3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return PNGPD_OK;
+}
+
+int pngpd_train_forward(int B, int P, int k, const float* x_dev, float* const* params_dev, int n_slots,
+                        float momentum, float* logp_dev, float* trans_dev, float* feat_dev, void* workspace_dev,
+                        size_t workspace_bytes, void* stream) {
+    return train_forward_impl(B, P, k, x_dev, params_dev, n_slots, momentum, logp_dev, trans_dev, feat_dev,
+                              workspace_dev, workspace_bytes, stream, nullptr);
+}
+
+int pngpd_train_forward_timed(int B, int P, int k, const float* x_dev, float* const* params_dev, int n_slots,
+                              float momentum, float* logp_dev, float* trans_dev, float* feat_dev, void* workspace_dev,
+                              size_t workspace_bytes, float* conv3_ms_out, void* stream) {
+    if (!conv3_ms_out) return fail(PNGPD_ERR_INVALID, "pngpd_train_forward_timed: NULL conv3_ms_out");
+    hipEvent_t ev[4];
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipEventCreate(&ev[i]);
+        if (e != hipSuccess) {
+            while (i-- > 0) (void)hipEventDestroy(ev[i]);
+            return fail(PNGPD_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+        }
+    }
+    int rc = train_forward_impl(B, P, k, x_dev, params_dev, n_slots, momentum, logp_dev, trans_dev, feat_dev,
+                                workspace_dev, workspace_bytes, stream, ev);
+    if (rc == PNGPD_OK) {
+        hipError_t e = hipEventSynchronize(ev[3]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&conv3_ms_out[0], ev[0], ev[1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&conv3_ms_out[1], ev[2], ev[3]);
+        if (e != hipSuccess) rc = fail(PNGPD_ERR_HIP, "event timing failed: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
 }
 
 int pngpd_train_argmax(int B, int P, int k, const void* workspace_dev, size_t workspace_bytes, int* stn_arg_dev,

@@ -598,8 +598,10 @@ hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const 
     const size_t lds = 2 * TC_CHUNK_BYTES + (size_t)TC_WAVES * 32 * ntb * 8;
     e = hipFuncSetAttribute((const void*)conv3_pool_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    if (w.ev_begin != nullptr && (e = hipEventRecord(w.ev_begin, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(conv3_pool_train_kernel, dim3(B, cs), dim3(TC_THREADS), lds, s, h2, (const float*)w.w3p,
                        (const float*)w.sh, P, relu_out, ntb, pooled, arg);
+    if (w.ev_end != nullptr && (e = hipEventRecord(w.ev_end, s)) != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -63,8 +63,9 @@ def _check(model, x):
     return x.detach().to(torch.float32).contiguous()
 
 
-def train_forward(model, x, ws=None):
-    """Train-mode forward; returns (logp, trans, workspace).  Updates running statistics."""
+def train_forward(model, x, ws=None, conv3_ms=None):
+    """Train-mode forward; returns (logp, trans, workspace, x).  Updates running statistics.
+    conv3_ms: a list that receives the durations (ms, HIP events) of the two conv3 product/max kernels."""
     lib = _lib.load()
     x = _check(model, x)
     B, _, P = x.shape
@@ -79,9 +80,15 @@ def train_forward(model, x, ws=None):
     trans = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.pngpd_train_forward(B, P, k, ctypes.c_void_p(x.data_ptr()), params, _lib.SLOTS, BN_MOMENTUM,
-                                           ctypes.c_void_p(logp.data_ptr()), ctypes.c_void_p(trans.data_ptr()), None,
-                                           ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream))
+        args = (B, P, k, ctypes.c_void_p(x.data_ptr()), params, _lib.SLOTS, BN_MOMENTUM,
+                ctypes.c_void_p(logp.data_ptr()), ctypes.c_void_p(trans.data_ptr()), None,
+                ctypes.c_void_p(ws.data_ptr()), ws.numel())
+        if conv3_ms is None:
+            _lib.check(lib.pngpd_train_forward(*args, stream))
+        else:
+            pair = (ctypes.c_float * 2)()
+            _lib.check(lib.pngpd_train_forward_timed(*args, pair, stream))
+            conv3_ms += [pair[0], pair[1]]
     _bump_num_batches(model)
     invalidate_packed_weights()        # running statistics changed under torch's version counters
     return logp, trans, ws, x
@@ -210,6 +217,7 @@ class Trainer:
             self._gview[id(p)] = g
             off += k
         self._ws = None
+        self.conv3_ms = None      # set to a list to collect the conv3 kernel durations of every step
 
     def world_size(self):
         if dist.is_available() and dist.is_initialized():
@@ -221,7 +229,7 @@ class Trainer:
         model = self.model
         if not model.training:
             raise RuntimeError("Trainer.step needs model.train()")
-        logp, _, self._ws, x = train_forward(model, data, self._ws)
+        logp, _, self._ws, x = train_forward(model, data, self._ws, self.conv3_ms)
         loss, dlogp = nll_loss(logp, target)
         train_backward(model, x, logp, dlogp, None, self._ws, lambda p: self._gview[id(p)])
         ws = self.world_size()
