@@ -168,20 +168,21 @@ def online_workload(args, dev, rank, n_gpus, dist):
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(dist, elapsed, dev)
-    # stage split with events on the launch stream
+    # stage split with events on the launch stream: crop + subsample in one pass, then scoring and vote
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     e[0].record()
-    res = hc.collect_pc(grasps_dev, scene, limits, return_points=False)
+    pts, valid, counts, overflow = hc.crop_subsample(grasps_dev, scene, limits, P, repeat=R, seed=0)
     e[1].record()
-    pts, valid = hc.subsample(res, P, repeat=R, seed=0)
     from pointnetgpd_amd.scoring import score_candidates
     pred, probs, _ = score_candidates(model, pts)
     hc.vote(pred, probs, valid, R)
     e[2].record()
     torch.cuda.synchronize(dev)
+    assert int(overflow.item()) == 0
     crop_ms, score_ms = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
-    total_idx = int(res.offsets[-1].item())
-    crop_bytes = S * 12 + G * 15 * 8 + G * 4 + total_idx * 4            # algorithmic: scene once, frames, counts, indices
+    total_idx = int(counts.sum().item())
+    # algorithmic bytes of the stage: scene once, grasps, counts, and the network input it writes
+    crop_bytes = S * 12 + G * 15 * 8 + G * 4 + G * R * P * 3 * 4
     if rank == 0:
         crop_gbps = crop_bytes / (crop_ms * 1e-3) / 1e9
         line = {
@@ -193,9 +194,9 @@ def online_workload(args, dev, rank, n_gpus, dist):
                        "crop_ms": round(crop_ms, 3), "score_ms": round(score_ms, 3), "pair_tests_per_s": round(S * G / (crop_ms * 1e-3), 1),
                        "crop_algorithmic_GBps": round(crop_bytes / (crop_ms * 1e-3) / 1e9, 2),
                        "mean_points_per_grasp": round(total_idx / G, 1), "good_grasps": int(out.order.numel())},
-            # the crop stage against the HBM roofline (its traversal is latency-bound: the algorithmic bytes are
-            # small); the stage that dominates the frame is the scoring, whose kernel the score workload reports
-            "roofline": {"bound": "hbm", "kernel": "crop count + emit (all kernels of collect_pc)",
+            # the crop + subsample stage against the HBM roofline (its traversal is latency-bound: the algorithmic
+            # bytes are small); the stage that dominates the frame is the scoring, whose kernel the score workload reports
+            "roofline": {"bound": "hbm", "kernel": "crop + subsample (grid build and k_cull_gather)",
                          "achieved": round(crop_gbps, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(crop_gbps / 8000.0, 5), "traffic": None, "stage_ms": round(crop_ms, 3),
                          "bytes_per_frame": crop_bytes},

@@ -182,6 +182,19 @@ int pngpd_crop_gather(const float* scene_dev, int S, int G, const void* workspac
                       float* pts_out_dev, int32_t* sel_out_dev, uint8_t* valid_dev, void* stream);
 
 /*
+ * pngpd_crop_count + pngpd_crop_emit + pngpd_crop_gather in one pass for callers that want the network input
+ * only (the online loop, apps/kinect2grasp.py:712-817, never looks at the index lists again): no index list in
+ * memory and no host read of its total in between.  pts_out_dev, valid_dev as pngpd_crop_gather writes them for
+ * the same seed (device-drawn selection); cnt_dev int32 [G] = points inside the gripper.  A grasp holding more
+ * than 1536 points does not fit the kernel's on-chip list: *overflow_dev (int32) is then set to 1, that grasp's
+ * rows of pts_out_dev are left unwritten and the caller falls back on the three calls above (same workspace).
+ */
+int pngpd_crop_subsample(const float* scene_dev, int S, const double* grasps_dev, int G, const double* limits,
+                         void* workspace_dev, size_t workspace_bytes, int repeat, int P, int min_points,
+                         uint64_t seed, int first_grasp_id, float* pts_out_dev, uint8_t* valid_dev,
+                         int32_t* cnt_dev, int32_t* overflow_dev, void* stream);
+
+/*
  * The dataset's form of the same step (PointGraspOneViewDataset.__getitem__,
  * model/dataset.py:1098-1111): one draw per grasp, output float32 [G,3,P] (the `.T` of :1106),
  * without replacement only when cnt > P (:1104; cnt == P is drawn WITH replacement, unlike the

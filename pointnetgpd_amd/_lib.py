@@ -47,6 +47,8 @@ SIGNATURES = {
                                 c_void_p, c_int64, c_void_p, c_void_p]),
     "pngpd_crop_gather": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_void_p, c_uint64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pngpd_crop_subsample": (c_int, [c_void_p, c_int, c_void_p, c_int, POINTER(c_double), c_void_p, c_size_t, c_int,
+                                     c_int, c_int, c_uint64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pngpd_crop_count_frames": (c_int, [c_void_p, c_int, c_void_p, c_int, POINTER(c_double), c_void_p, c_size_t,
                                         c_void_p, c_void_p, c_void_p]),
     "pngpd_crop_gather_dataset": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,

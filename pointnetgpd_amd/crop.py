@@ -120,6 +120,38 @@ def subsample(crop: CropResult, num_points: int, repeat: int = 3, sel=None, seed
     return (pts, valid, sel_out) if return_selection else (pts, valid)
 
 
+def crop_subsample(grasp_, pc, limits, num_points: int, repeat: int = 3, seed: int = 0,
+                   min_points: int = MIN_POINTS, grasp_offset: int = 0):
+    """collect_pc + subsample in one device pass, without the index lists and without a host read in between
+    (apps/kinect2grasp.py:712, 746-774 for all grasps): returns (pts float32 [G*repeat, P, 3], valid uint8 [G],
+    counts int32 [G], overflow int32 [1]).  The draws are the device generator's, so the result equals
+    subsample(collect_pc(...), seed=seed).  overflow[0] != 0 means some grasp held more points than the kernel
+    keeps on chip and its rows were not written: call collect_pc + subsample then (score_grasps does)."""
+    lib = _lib.load()
+    dev = pc.device if isinstance(pc, torch.Tensor) and pc.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    scene = torch.as_tensor(pc, dtype=torch.float32, device=dev).contiguous()
+    grasps = torch.as_tensor(np.asarray(grasp_.cpu() if isinstance(grasp_, torch.Tensor) else grasp_, dtype=np.float64)
+                             .reshape(-1, 5, 3), device=dev).contiguous() \
+        if not (isinstance(grasp_, torch.Tensor) and grasp_.is_cuda and grasp_.dtype == torch.float64) \
+        else grasp_.reshape(-1, 5, 3).contiguous()
+    if scene.dim() != 2 or scene.shape[1] != 3:
+        raise ValueError("scene must be [S,3]")
+    S, G = scene.shape[0], grasps.shape[0]
+    lim = (ctypes.c_double * 6)(*[float(v) for v in limits])
+    nbytes = lib.pngpd_crop_workspace_bytes(S, G)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    pts = torch.empty((G * repeat, num_points, 3), dtype=torch.float32, device=dev)
+    valid = torch.empty(G, dtype=torch.uint8, device=dev)
+    counts = torch.empty(G, dtype=torch.int32, device=dev)
+    overflow = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.pngpd_crop_subsample(_ptr(scene), S, _ptr(grasps), G, lim, _ptr(ws), nbytes, repeat, num_points,
+                                            min_points, ctypes.c_uint64(seed & (2 ** 64 - 1)), grasp_offset, _ptr(pts),
+                                            _ptr(valid), _ptr(counts), _ptr(overflow), stream))
+    return pts, valid, counts, overflow
+
+
 def vote(pred: torch.Tensor, probs: torch.Tensor, valid, repeat: int):
     """Repeat vote of apps/kinect2grasp.py:799-817 for all grasps: (label int32 [G], score float32 [G])."""
     lib = _lib.load()

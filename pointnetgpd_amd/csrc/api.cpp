@@ -432,6 +432,25 @@ int pngpd_crop_gather(const float* scene_dev, int S, int G, const void* workspac
     return PNGPD_OK;
 }
 
+int pngpd_crop_subsample(const float* scene_dev, int S, const double* grasps_dev, int G, const double* limits,
+                         void* workspace_dev, size_t workspace_bytes, int repeat, int P, int min_points, uint64_t seed,
+                         int first_grasp_id, float* pts_out_dev, uint8_t* valid_dev, int32_t* cnt_dev,
+                         int32_t* overflow_dev, void* stream) {
+    if (!scene_dev || !grasps_dev || !limits || !pts_out_dev || !valid_dev || !cnt_dev || !overflow_dev)
+        return fail(PNGPD_ERR_INVALID, "pngpd_crop_subsample: NULL argument");
+    if (repeat < 1 || P < 1 || min_points < 1)
+        return fail(PNGPD_ERR_SHAPE, "pngpd_crop_subsample: repeat=%d P=%d min_points=%d", repeat, P, min_points);
+    int rc = crop_ws_check(S, G, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    pngpd::CropLimits L{limits[0], limits[1], limits[2], limits[3], limits[4], limits[5]};
+    CropWs w(workspace_dev, S, G);
+    HIP_TRY(pngpd::launch_crop_frames(grasps_dev, w.frames, G, (hipStream_t)stream));
+    HIP_TRY(pngpd::launch_crop_gather_fused(scene_dev, S, w.frames, G, L, w.grid, repeat, P, min_points, seed,
+                                            first_grasp_id, pts_out_dev, valid_dev, cnt_dev, overflow_dev,
+                                            (hipStream_t)stream));
+    return PNGPD_OK;
+}
+
 int pngpd_crop_gather_dataset(const float* scene_dev, int S, int G, const void* workspace_dev, size_t workspace_bytes,
                               const int32_t* idx_dev, const int64_t* offsets_dev, const int32_t* cnt_dev, int P,
                               int min_points, const int32_t* sel_dev, uint64_t seed, int first_grasp_id,

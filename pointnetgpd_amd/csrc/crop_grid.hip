@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "crop_math.h"
+#include "crop_select.h"
 #include "kernels.h"
 
 namespace pngpd {
@@ -470,6 +471,105 @@ __global__ __launch_bounds__(256) void k_cull_emit(const float* __restrict__ sce
     }
 }
 
+#ifndef PNGPD_FUSED_CAP
+#define PNGPD_FUSED_CAP 1536
+#endif
+constexpr int FUSED_CAP = PNGPD_FUSED_CAP;      // points of one grasp the one-pass kernel holds on chip
+
+// Crop and subsample in one pass, for callers that want the network input and not the index lists: one
+// workgroup per grasp collects the hits in LDS (as k_cull_emit does), sorts them, moves the points to the gripper
+// frame (float64, rounded to float32) into LDS and writes the R x P draws.  No count pass, no offsets, no index
+// list in memory, no host read of the total in between.  The draws index the ascending list, so the output is
+// what k_cull_emit + crop_gather_kernel write.  A grasp with more than FUSED_CAP points cannot be held:
+// it raises *overflow and leaves its rows unwritten; the caller then takes the three-call path.
+__global__ __launch_bounds__(256) void k_cull_gather(const float* __restrict__ scene,
+                                                     const double* __restrict__ frames, int G, CropLimits L,
+                                                     const GridParams* __restrict__ gp, const int* __restrict__ start,
+                                                     const float4* __restrict__ sorted, int R, int P, int min_points,
+                                                     unsigned long long seed, int first_grasp_id,
+                                                     float* __restrict__ pts_out, unsigned char* __restrict__ valid,
+                                                     int* __restrict__ cnt, int* __restrict__ overflow) {
+    // one 18 KiB buffer: first the hit list (FUSED_CAP indices as found, then as many sorted), later the
+    // float32 points - the sorted indices pass through registers in between.  LDS per workgroup decides how many
+    // grasps a CU traverses at once, and the traversal is latency-bound.
+    __shared__ __attribute__((aligned(16))) char s_buf[FUSED_CAP * 12];
+    __shared__ int s_small[800];
+    int* list = (int*)s_buf;
+    float* s_pts = (float*)s_buf;
+    __shared__ int s_fill;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const double* f = frames + (size_t)g * 12;
+    const GraspCells gc = grasp_cells(f, L, gp);
+    const int ny = gc.c1[1] - gc.c0[1] + 1, nrows = ny * (gc.c1[2] - gc.c0[2] + 1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (tid == 0) s_fill = 0;
+    __syncthreads();
+    for (int row = wave; row < nrows; row += 4) {
+        const int iy = gc.c0[1] + row % ny, iz = gc.c0[2] + row / ny;
+        int p0, p1;
+        if (!row_range(f, L, gc, gp, start, iy, iz, lane, p0, p1)) continue;
+        for (int p = p0; p < p1; p += 64) {           // wave-uniform trip count: ballots stay whole
+            bool hit = false;
+            int s = 0;
+            if (p + lane < p1) {
+                const float4 v = sorted[p + lane];
+                hit = in_box(to_gripper(f, (double)v.x, (double)v.y, (double)v.z), L);
+                s = __float_as_int(v.w);
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (bal == 0ull) continue;
+            int at = 0;
+            if (lane == 0) at = atomicAdd(&s_fill, __popcll(bal));
+            at = __shfl(at, 0);
+            const int pos = at + (int)__popcll(bal & below);
+            if (hit && pos < FUSED_CAP) list[pos] = s;
+        }
+    }
+    __syncthreads();
+    const int n = s_fill;                              // exact even when the list overflowed
+    if (tid == 0) cnt[g] = n;
+    float* out = pts_out + (size_t)g * R * P * 3;
+    if (n < min_points) {     // apps/kinect2grasp.py:746-751: scored 0 without running the network
+        for (int i = tid; i < R * P * 3; i += 256) out[i] = 0.f;
+        if (tid == 0) valid[g] = 0;
+        return;
+    }
+    if (tid == 0) valid[g] = 1;
+    if (n > FUSED_CAP) {
+        if (tid == 0) atomicOr(overflow, 1);
+        return;
+    }
+    const int* ordered = block_bucket_sort(list, list + FUSED_CAP, s_small, n, tid);
+    int mine[FUSED_CAP / 256];
+#pragma unroll
+    for (int k = 0; k < FUSED_CAP / 256; ++k) mine[k] = tid + 256 * k < n ? ordered[tid + 256 * k] : 0;
+    __syncthreads();                                   // the index list is in registers: its LDS becomes s_pts
+#pragma unroll
+    for (int k = 0; k < FUSED_CAP / 256; ++k) {
+        const int i = tid + 256 * k;
+        if (i < n) {
+            const float* p = scene + (size_t)mine[k] * 3;
+            const PointD q = to_gripper(f, (double)p[0], (double)p[1], (double)p[2]);
+            s_pts[3 * i + 0] = (float)q.x;
+            s_pts[3 * i + 1] = (float)q.y;
+            s_pts[3 * i + 2] = (float)q.z;
+        }
+    }
+    __syncthreads();
+    for (int r = 0; r < R; ++r) {
+        Selector pick;
+        pick.init(seed, first_grasp_id + g, r, n, P, 0);
+        float* o = out + (size_t)r * P * 3;
+        for (int i = tid; i < P; i += 256) {
+            const int j = pick.draw(i);
+            o[3 * i + 0] = s_pts[3 * j + 0];
+            o[3 * i + 1] = s_pts[3 * j + 1];
+            o[3 * i + 2] = s_pts[3 * j + 2];
+        }
+    }
+}
+
 size_t crop_grid_bytes(int S) {
     auto r = [](size_t n) { return (n + 255) & ~(size_t)255; };
     const size_t nblk = (size_t)(S + BOUNDS_BLOCK_PTS - 1) / BOUNDS_BLOCK_PTS;
@@ -498,12 +598,9 @@ struct GridWs {
 };
 }  // namespace
 
-// Bins the scene and counts, per grasp, the points inside the gripper region.  `grid_ws` holds
-// crop_grid_bytes(S) bytes and keeps the binned scene for launch_crop_emit_grid.
-hipError_t launch_crop_count_grid(const float* scene, int S, const double* frames, int G, const CropLimits& L,
-                                  void* grid_ws, int* cnt, hipStream_t s) {
+// Bins the scene: bounds, cell of every point, prefix over the cells, points regrouped by cell.
+static hipError_t build_grid(const float* scene, int S, const CropLimits& L, const GridWs& w, hipStream_t s) {
     const int nblk = (S + BOUNDS_BLOCK_PTS - 1) / BOUNDS_BLOCK_PTS;
-    GridWs w(grid_ws, S);
     const double ext_x = L.xhi - L.xlo, ext_y = L.yhi - L.ylo, ext_z = L.zhi - L.zlo;
     // cells of a quarter of the region's longest side (the scene's extent / 63 if that is larger): smaller cells
     // test fewer points but visit more rows, and a row costs a dependent pair of loads (measured at S = 1M,
@@ -520,8 +617,36 @@ hipError_t launch_crop_count_grid(const float* scene, int S, const double* frame
                        w.cursor);
     hipLaunchKernelGGL(k_scatter, dim3((S + 255) / 256), dim3(256), 0, s, scene, S, (const int*)w.cell_of, w.cursor,
                        w.sorted);
+    return hipGetLastError();
+}
+
+// Bins the scene and counts, per grasp, the points inside the gripper region.  `grid_ws` holds
+// crop_grid_bytes(S) bytes and keeps the binned scene for launch_crop_emit_grid.
+hipError_t launch_crop_count_grid(const float* scene, int S, const double* frames, int G, const CropLimits& L,
+                                  void* grid_ws, int* cnt, hipStream_t s) {
+    GridWs w(grid_ws, S);
+    hipError_t e = build_grid(scene, S, L, w, s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_cull_count, dim3((G + 3) / 4), dim3(256), 0, s, frames, G, L, (const GridParams*)w.gp,
                        (const int*)w.start, (const float4*)w.sorted, cnt);
+    return hipGetLastError();
+}
+
+// Bins the scene, then crops and subsamples every grasp in one kernel (k_cull_gather).
+hipError_t launch_crop_gather_fused(const float* scene, int S, const double* frames, int G, const CropLimits& L,
+                                    void* grid_ws, int R, int P, int min_points, unsigned long long seed,
+                                    int first_grasp_id, float* pts_out, unsigned char* valid, int* cnt, int* overflow,
+                                    hipStream_t s) {
+    if (!scene || !frames || !grid_ws || !pts_out || !valid || !cnt || !overflow || S < 1 || G < 1 || R < 1 || P < 1)
+        return hipErrorInvalidValue;
+    GridWs w(grid_ws, S);
+    hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    e = build_grid(scene, S, L, w, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_cull_gather, dim3(G), dim3(256), 0, s, scene, frames, G, L, (const GridParams*)w.gp,
+                       (const int*)w.start, (const float4*)w.sorted, R, P, min_points, seed, first_grasp_id, pts_out,
+                       valid, cnt, overflow);
     return hipGetLastError();
 }
 

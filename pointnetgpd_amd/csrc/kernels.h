@@ -82,6 +82,12 @@ hipError_t launch_crop_emit_grid(const float* scene, int S, const double* frames
                                  const void* grid_ws, const int* cnt, const long long* offsets, int* idx,
                                  long long capacity, double* pts_g, hipStream_t s);
 
+hipError_t launch_crop_gather_fused(const float* scene, int S, const double* frames, int G, const CropLimits& L,
+                                    void* grid_ws, int R, int P, int min_points, unsigned long long seed,
+                                    int first_grasp_id, float* pts_out, unsigned char* valid, int* cnt, int* overflow,
+                                    hipStream_t s);
+hipError_t launch_crop_frames(const double* grasps, double* frames, int G, hipStream_t s);
+
 // PNGPD_CROP_BRUTE=1 in the environment selects the all-pairs pass with its [G, S/64] bit mask (the tests
 // cross-check the culled pass against it); the mask is part of the workspace only then.
 bool crop_brute_mode();

@@ -209,6 +209,47 @@ def test_online_pipeline_ranks_good_grasps():
     assert torch.equal(pts_slice, pts_all[30:60])
 
 
+@pytest.mark.parametrize("S,G,cube,P", [(80_000, 40, 0.2, 500), (300_000, 200, 0.4, 750), (2_000, 10, 3.0, 64),
+                                        (1_000_000, 500, 0.5, 750)])
+def test_one_pass_crop_subsample_equals_the_three_calls(S, G, cube, P):
+    seed = 17 + G
+    scene = torch.from_numpy(synth.scene_points(seed, S, cube)).cuda()
+    grasps = synth.random_grasps(seed, G, cube, 0.03)
+    res = hc.collect_pc(grasps, scene, LIMITS, return_points=False)
+    pts_ref, valid_ref = hc.subsample(res, P, repeat=3, seed=9, grasp_offset=7)
+    pts, valid, counts, overflow = hc.crop_subsample(grasps, scene, LIMITS, P, repeat=3, seed=9, grasp_offset=7)
+    assert int(overflow.item()) == 0
+    assert torch.equal(counts, res.counts) and torch.equal(valid, valid_ref)
+    assert torch.equal(pts, pts_ref)                      # bit for bit: same list order, same draws, same arithmetic
+
+
+def test_one_pass_crop_subsample_reports_grasps_it_cannot_hold():
+    """A dense scene puts more than 1536 points into some grasps: the one-pass kernel says so, its counts stay
+    exact, and score_grasps falls back on the three calls."""
+    from pointnetgpd_amd.online import score_grasps
+    from pointnetgpd_amd.dist import score_grasps_sharded
+    P, k, seed = 500, 2, 29
+    scene = torch.from_numpy(synth.scene_points(seed, 90_000, 0.05)).cuda()
+    grasps = synth.random_grasps(seed, 12, 0.05, 0.0)
+    res = hc.collect_pc(grasps, scene, LIMITS, return_points=False)
+    assert int(res.counts.max()) > 1536
+    pts, valid, counts, overflow = hc.crop_subsample(grasps, scene, LIMITS, P, repeat=3, seed=5)
+    assert int(overflow.item()) == 1
+    assert torch.equal(counts, res.counts)
+    pts_ref, valid_ref = hc.subsample(res, P, repeat=3, seed=5)
+    assert torch.equal(valid, valid_ref)
+    small = (res.counts <= 1536).nonzero().flatten().cpu().tolist()
+    for g in small:                                        # grasps that fit are complete all the same
+        assert torch.equal(pts[3 * g:3 * g + 3], pts_ref[3 * g:3 * g + 3])
+    m = PointNetCls(P, 3, k)
+    m.load_state_dict(synth.torch_state_dict(seed, k, 0.02))
+    m = m.cuda().eval()
+    out = score_grasps(m, scene, grasps, LIMITS, repeat=3, seed=5)
+    label, score, valid2 = score_grasps_sharded(m, scene, grasps, LIMITS, repeat=3, seed=5)
+    assert torch.equal(out.label, label) and torch.equal(out.score, score) and torch.equal(out.valid, valid2)
+    assert torch.equal(out.counts, res.counts)
+
+
 @pytest.mark.parametrize("S,G,cube", [(300_000, 200, 0.4), (5_000, 50, 0.05), (2_000, 10, 3.0), (90_000, 12, 0.05)])
 def test_grid_culled_pass_equals_all_pairs_pass(S, G, cube, monkeypatch):
     """The spatially culled mask pass and the brute-force all-pairs pass give identical crops
