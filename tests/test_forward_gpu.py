@@ -94,7 +94,7 @@ def test_against_oracle_fresh_inputs(B, precision, tol):
     assert ok
 
 
-RAGGED = [(1, 1), (2, 15), (3, 16), (3, 17), (5, 255), (5, 256), (5, 257), (4, 513), (257, 48), (300, 300), (600, 33)]
+RAGGED = [(1, 1), (2, 2500), (2, 15), (3, 16), (3, 17), (5, 255), (5, 256), (5, 257), (4, 513), (257, 48), (300, 300), (600, 33)]
 
 
 @pytest.mark.parametrize("B,P", RAGGED, ids=[f"B{b}_P{p}" for b, p in RAGGED])
