@@ -127,7 +127,7 @@ __device__ __forceinline__ void write_pooled(const ConvStackArgs& a, int b, cons
 // higher clock on it under sustained load (same cycles per flop, ~12 % more flop/s).
 //
 // LDS: [0,128K) two batches of A fragments | [128K,144K) W2 fragments | conv2 bias |
-//      per-wave conv1 tables (trans folded in; private to a wave, so no workgroup barrier).
+//      per-wave conv1 tables (trans folded in; private to a wave, so no workgroup barrier) | conv3 bias.
 // ------------------------------------------------------------------------------------------
 constexpr int WS_WAVES = 8;
 constexpr int WS_THREADS = WS_WAVES * 64;
@@ -147,7 +147,8 @@ constexpr int WS_OFF_W2 = 2 * WS_BATCH_BYTES;
 constexpr int WS_OFF_B2 = WS_OFF_W2 + (int)W2P_BF16_BYTES;
 constexpr int WS_OFF_W1B = WS_OFF_B2 + C2 * 4;             // BN-folded conv1 table, shared
 constexpr int WS_OFF_W1 = WS_OFF_W1B + C1 * 16;            // per-wave copies with trans folded in
-constexpr int WS_LDS_BYTES = WS_OFF_W1 + WS_WAVES * C1 * 16;
+constexpr int WS_OFF_B3 = WS_OFF_W1 + WS_WAVES * C1 * 16;   // conv3 bias: read once per candidate by every wave
+constexpr int WS_LDS_BYTES = WS_OFF_B3 + C3 * 4;
 typedef f32x4 f32x4v;
 
 // Orders this wave's own LDS accesses (a wave-private table is written, later read, by one wave).
@@ -365,6 +366,8 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
     }
     if (tid < C2) s_b2[tid] = a.b2p[tid];
     if (tid < C1) s_w1base[tid] = a.w1tab[tid];
+    float* s_b3 = (float*)(smem + WS_OFF_B3);
+    for (int i = tid; i < C3; i += WS_THREADS) s_b3[i] = a.b3[i];
     __syncthreads();
 
     const int ntiles = (a.P + 15) >> 4;
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
         for (int nt = 0; nt < 8; ++nt) {
             const int ch = wave * 128 + nt * 16 + c;
             float m = __builtin_fmaxf(rm[nt], __shfl_xor(rm[nt], 16));
-            m = __builtin_fmaxf(m, __shfl_xor(m, 32)) + a.b3[ch];
+            m = __builtin_fmaxf(m, __shfl_xor(m, 32)) + s_b3[ch];
             if (a.relu_out) m = __builtin_fmaxf(m, 0.f);
             if (q == 0) a.pooled[(size_t)b * C3 + ch] = m;
         }

@@ -53,12 +53,15 @@ def score_grasps_sharded(model, scene, grasps, limits, repeat: int = 3, seed: in
     lo, hi = shard_range(G, rank, ws)
     local = grasps[lo:hi]
     P = model.num_points
-    res = _crop.collect_pc(local, scene, limits, return_points=False)
-    # per-grasp selections keyed by global id: draw on the host twin only when ranks > 1 would
-    # otherwise disagree; the device generator takes the slice offset through the seed instead
-    pts, valid = _crop.subsample(res, P, repeat=repeat, seed=seed, grasp_offset=lo)
+    # the device generator keys every draw by the global grasp id (slice offset `lo`)
+    pts, valid, _, overflow = _crop.crop_subsample(local, scene, limits, P, repeat=repeat, seed=seed, grasp_offset=lo)
     pred, probs, _ = score_candidates(model, pts)
     label, score = _crop.vote(pred, probs, valid, repeat)
+    if int(overflow.item()) != 0:      # a grasp with more points than the one-pass kernel holds: three-call path
+        res = _crop.collect_pc(local, scene, limits, return_points=False)
+        pts, valid = _crop.subsample(res, P, repeat=repeat, seed=seed, grasp_offset=lo)
+        pred, probs, _ = score_candidates(model, pts)
+        label, score = _crop.vote(pred, probs, valid, repeat)
     if not gather:
         return label, score, valid
     return gather_concat(label, G), gather_concat(score, G), gather_concat(valid, G)
