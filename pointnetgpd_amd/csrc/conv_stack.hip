@@ -308,14 +308,15 @@ __device__ __forceinline__ f32x4v mfma_chain4(const bf16x8 (&af)[4], const bf16x
     return z;
 }
 
-__device__ __forceinline__ void consume_tile(const bf16x8 (&af)[4], const bf16x8 (&bw)[8][4], f32x4v& carry,
-                                             float (&rm)[8]) {
+template <int NT>
+__device__ __forceinline__ void consume_tile(const bf16x8 (&af)[4], const bf16x8 (&bw)[NT][4], f32x4v& carry,
+                                             float (&rm)[NT]) {
     f32x4v accA = carry, accB;
 #pragma unroll
-    for (int n = 0; n < 8; n += 2) {
+    for (int n = 0; n < NT; n += 2) {
         accB = mfma_chain4(af, bw[n]);
         __builtin_amdgcn_sched_barrier(0);
-        const int pn = (n + 7) & 7;
+        const int pn = (n + NT - 1) & (NT - 1);
         rm[pn] = max3(rm[pn], max3(accA[0], accA[1], accA[2]), accA[3]);
         __builtin_amdgcn_sched_barrier(0);
         accA = mfma_chain4(af, bw[n + 1]);
@@ -342,7 +343,18 @@ __device__ unsigned long long g_stamp_clock[4];
 #define STAMP(g, ev)
 #endif
 
+// which quarter / half of the channels a workgroup covers; the full-width kernel has a single piece
+template <int NT>
+__device__ __forceinline__ int piece_of() {
+    return NT == 8 ? 0 : (int)blockIdx.y;
+}
+
+// NT = channel tiles of 16 per wave: 8 is the throughput shape (a workgroup covers all 1024 channels, grid.y = 1).
+// A batch too small to give every CU a candidate runs NT = 2 with grid.y = 4: workgroup (x, y) covers channels
+// [256y, 256y + 256) and repeats layers 1-2; the arithmetic of a channel does not depend on the cut.
+template <int NT>
 __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackArgs a) {
+    static_assert(NT == 8 || NT == 4 || NT == 2, "channel tiles per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -353,12 +365,13 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
     float4* s_w1base = (float4*)(smem + WS_OFF_W1B);
     float4* s_w1w = (float4*)(smem + WS_OFF_W1) + wave * C1;
 
-    bf16x8 bw[8][4];
+    const int ct0 = (piece_of<NT>() * WS_WAVES + wave) * NT;      // first channel tile of this wave
+    bf16x8 bw[NT][4];
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            bw[nt][ks] = *(const bf16x8*)((const char*)a.w3p + ((((wave * 8 + nt) * 4 + ks) * 64) + lane) * 16);
+            bw[nt][ks] = *(const bf16x8*)((const char*)a.w3p + ((((ct0 + nt) * 4 + ks) * 64) + lane) * 16);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int piece = wave * 2 + i;
@@ -413,9 +426,9 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
     int buf = 0;
     for (int ci = 0; ci < ncand; ++ci) {
         const int b = blockIdx.x + ci * stride;
-        float rm[8];
+        float rm[NT];
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) rm[nt] = -INFINITY;
+        for (int nt = 0; nt < NT; ++nt) rm[nt] = -INFINITY;
         for (int bt = 0; bt < nbatch; ++bt, buf ^= 1) {
             const int nt_b = min(W16_BATCH_TILES, ntiles - W16_BATCH_TILES * bt);
             const int npairs = (nt_b + 1) >> 1;
@@ -462,7 +475,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
                 }
                 consume_tile(afA, bw, carry, rm);
             }
-            rm[7] = max3(rm[7], max3(carry[0], carry[1], carry[2]), carry[3]);
+            rm[NT - 1] = max3(rm[NT - 1], max3(carry[0], carry[1], carry[2]), carry[3]);
             STAMP(g, 3);
             lds_barrier();          // orders the A-fragment buffers only: the point loads of the next produce step stay in flight
             STAMP(g, 4);
@@ -471,8 +484,9 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
 #endif
         }
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-            const int ch = wave * 128 + nt * 16 + c;
+        for (int nt = 0; nt < NT; ++nt) {
+            // recomputed here: a value kept alive across the loops costs this kernel a register it does not have
+            const int ch = (piece_of<NT>() * WS_WAVES + wave) * (16 * NT) + nt * 16 + c;
             float m = __builtin_fmaxf(rm[nt], __shfl_xor(rm[nt], 16));
             m = __builtin_fmaxf(m, __shfl_xor(m, 32)) + s_b3[ch];
             if (a.relu_out) m = __builtin_fmaxf(m, 0.f);
@@ -657,12 +671,18 @@ hipError_t launch_conv_stack_bf16(const ConvStackArgs& a, hipStream_t s) {
     e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
     if (n_cu < 1) return hipErrorInvalidDevice;
-    e = hipFuncSetAttribute((const void*)conv_stack_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            WS_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    // persistent: one workgroup per CU, each strides over the candidates
-    hipLaunchKernelGGL(conv_stack_bf16_kernel, dim3(a.B < n_cu ? a.B : n_cu), dim3(WS_THREADS), WS_LDS_BYTES, s, a);
-    return hipGetLastError();
+    // persistent: one workgroup per CU, each strides over the candidates; a batch of fewer candidates than half
+    // the CUs is cut into channel pieces (2 or 4 workgroups per candidate)
+    auto launch = [&](auto kern, int pieces) {
+        hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+        if (er != hipSuccess) return er;
+        const int per_piece = n_cu / pieces > 0 ? n_cu / pieces : 1;
+        hipLaunchKernelGGL(kern, dim3(a.B < per_piece ? a.B : per_piece, pieces), dim3(WS_THREADS), WS_LDS_BYTES, s, a);
+        return hipGetLastError();
+    };
+    if (a.B * 4 <= n_cu) return launch(conv_stack_bf16_kernel<2>, 4);
+    if (a.B * 2 <= n_cu) return launch(conv_stack_bf16_kernel<4>, 2);
+    return launch(conv_stack_bf16_kernel<8>, 1);
 }
 
 hipError_t launch_conv_stack_f32(const ConvStackArgs& a, hipStream_t s) {
