@@ -108,12 +108,36 @@ __device__ __forceinline__ double vox_edge(const VoxelParams& p, int a, int i) {
 __global__ __launch_bounds__(VX_THREADS) void k_vox_setup(const float* partial, int nparts, int n, VoxelParams* prm,
                                                           float* mid, int* canon) {
     __shared__ float s_mm[6];
+    __shared__ float s_red[VX_THREADS / 64][6];
     __shared__ VoxelParams s_p;
-    if (threadIdx.x < 6) {
-        float v = partial[threadIdx.x];
-        for (int b = 1; b < nparts; ++b)
-            v = threadIdx.x < 3 ? fminf(v, partial[b * 6 + threadIdx.x]) : fmaxf(v, partial[b * 6 + threadIdx.x]);
-        s_mm[threadIdx.x] = v;
+    {
+        // all threads share the partial records (a serial walk by six threads is 512 dependent loads)
+        float v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = k < 3 ? INFINITY : -INFINITY;
+        for (int b = threadIdx.x; b < nparts; b += VX_THREADS)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float x = partial[b * 6 + k];
+                v[k] = k < 3 ? fminf(v[k], x) : fmaxf(v[k], x);
+            }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float o = __shfl_xor(v[k], off);
+                v[k] = k < 3 ? fminf(v[k], o) : fmaxf(v[k], o);
+            }
+            if (lane == 0) s_red[wave][k] = v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            float r = s_red[0][threadIdx.x];
+            for (int w = 1; w < VX_THREADS / 64; ++w)
+                r = threadIdx.x < 3 ? fminf(r, s_red[w][threadIdx.x]) : fmaxf(r, s_red[w][threadIdx.x]);
+            s_mm[threadIdx.x] = r;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {

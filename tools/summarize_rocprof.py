@@ -6,6 +6,7 @@ import sys
 
 
 def short(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)              # drop the argument list
     name = re.sub(r"^void\s+", "", name)
     return name[:90]
