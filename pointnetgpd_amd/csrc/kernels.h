@@ -125,7 +125,9 @@ hipError_t t_stats_from_records(const double* rec, int nrec, int M, int C, float
 // ---- training step (train.hip) ---------------------------------------------------------------
 constexpr int TN_ROWS_PER_CHUNK = 512;       // rows of one weight-gradient partial (multiple of 32)
 
-int t_red_blocks(int M);                     // row blocks of the column reductions
+int t_red_blocks(int M);                     // row blocks of 256 rows (conv1 weight-gradient partials)
+int t_colreduce_rows(int M);                 // rows per block of the column reductions over an [M, C] matrix
+int t_colreduce_blocks(int M);
 int t_tn_chunks(int M);                      // partials of a weight-gradient product
 // Gram-matrix partials: about 256 chunks of rows (3 workgroups each: a whole number per CU on a 256-CU part),
 // at least 256 and a multiple of 32 rows per chunk

@@ -69,14 +69,14 @@ constexpr int RED_ROWS = 256;   // rows per block
 __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ A, const float* __restrict__ H,
                                                    const float* __restrict__ Y, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, int M, int C, int mode,
-                                                   double* __restrict__ part) {
+                                                   int rows_per_block, double* __restrict__ part) {
     __shared__ double red[2][256 * 4];       // [s1|s2][row lane][column of the block]
     const int cq = C >> 2;
     const int QB = cq < 64 ? cq : 64, RL = 256 / QB;
     const int ql = threadIdx.x % QB, rl = threadIdx.x / QB;
     const int q = blockIdx.x * QB + ql;      // column quad
-    const int r0 = blockIdx.y * RED_ROWS;
-    const int r1 = min(M, r0 + RED_ROWS);
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
     if (q < cq && rl < RL) {
         const size_t col = (size_t)q * 4;
@@ -197,30 +197,60 @@ __global__ __launch_bounds__(256) void k_bnbwd_finalize(const double* __restrict
     if (dbias_zero != nullptr) dbias_zero[c] = 0.f;
 }
 
-// h = relu((y - mean)*rstd*gamma + beta)   (relu optional)
-__global__ void k_bn_act_fwd(const float* __restrict__ y, const float* __restrict__ mean,
-                             const float* __restrict__ rstd, const float* __restrict__ gamma,
-                             const float* __restrict__ beta, float* __restrict__ h, size_t n, int C, int relu) {
+// h = relu((y - mean)*rstd*gamma + beta)   (relu optional); four consecutive channels per thread (C % 4 == 0)
+__global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ y, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ h, size_t n4,
+                                                    int C, int relu) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i % C);
-    float v = (y[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
-    if (relu) v = fmaxf(v, 0.f);
-    h[i] = v;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % (size_t)C);
+    const float4 yv = ((const float4*)y)[i];
+    const float4 mv = *(const float4*)(mean + c), rv = *(const float4*)(rstd + c);
+    // gamma / beta are caller tensors (views of a flat parameter bucket need not be 16-byte aligned): scalar loads
+    const float4 gv = make_float4(gamma[c], gamma[c + 1], gamma[c + 2], gamma[c + 3]);
+    const float4 bv = make_float4(beta[c], beta[c + 1], beta[c + 2], beta[c + 3]);
+    float4 v;
+    v.x = (yv.x - mv.x) * rv.x * gv.x + bv.x;
+    v.y = (yv.y - mv.y) * rv.y * gv.y + bv.y;
+    v.z = (yv.z - mv.z) * rv.z * gv.z + bv.z;
+    v.w = (yv.w - mv.w) * rv.w * gv.w + bv.w;
+    if (relu) {
+        v.x = fmaxf(v.x, 0.f);
+        v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f);
+        v.w = fmaxf(v.w, 0.f);
+    }
+    ((float4*)h)[i] = v;
 }
 
-// dense BN backward, in place over dh:  dh <- gamma*rstd*(g - m1 - yhat*m2), g = dh*(h>0)
-__global__ void k_bn_bwd_dense(float* __restrict__ dh, const float* __restrict__ h, const float* __restrict__ y,
-                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                               const float* __restrict__ gamma, const float* __restrict__ m1,
-                               const float* __restrict__ m2, size_t n, int C) {
+// dense BN backward, in place over dh:  dh <- gamma*rstd*(g - m1 - yhat*m2), g = dh*(h>0); four channels per thread
+__global__ __launch_bounds__(256) void k_bn_bwd_dense(float* __restrict__ dh, const float* __restrict__ h,
+                                                      const float* __restrict__ y, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ m1, const float* __restrict__ m2,
+                                                      size_t n4, int C) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i % C);
-    float g = dh[i];
-    if (h != nullptr && !(h[i] > 0.f)) g = 0.f;
-    const float yh = (y[i] - mean[c]) * rstd[c];
-    dh[i] = gamma[c] * rstd[c] * (g - m1[c] - yh * m2[c]);
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % (size_t)C);
+    float4 gv = ((const float4*)dh)[i];
+    if (h != nullptr) {
+        const float4 hv = ((const float4*)h)[i];
+        if (!(hv.x > 0.f)) gv.x = 0.f;
+        if (!(hv.y > 0.f)) gv.y = 0.f;
+        if (!(hv.z > 0.f)) gv.z = 0.f;
+        if (!(hv.w > 0.f)) gv.w = 0.f;
+    }
+    const float4 yv = ((const float4*)y)[i];
+    const float4 mv = *(const float4*)(mean + c), rv = *(const float4*)(rstd + c);
+    const float4 ga = make_float4(gamma[c], gamma[c + 1], gamma[c + 2], gamma[c + 3]);     // caller tensor: scalar loads
+    const float4 a1 = *(const float4*)(m1 + c), a2 = *(const float4*)(m2 + c);
+    float4 o;
+    o.x = ga.x * rv.x * (gv.x - a1.x - (yv.x - mv.x) * rv.x * a2.x);
+    o.y = ga.y * rv.y * (gv.y - a1.y - (yv.y - mv.y) * rv.y * a2.y);
+    o.z = ga.z * rv.z * (gv.z - a1.z - (yv.z - mv.z) * rv.z * a2.z);
+    o.w = ga.w * rv.w * (gv.w - a1.w - (yv.w - mv.w) * rv.w * a2.w);
+    ((float4*)dh)[i] = o;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -539,33 +569,42 @@ hipError_t t_conv1_fwd(const float* X3, const float* W1, const float* b1, float*
     return hipGetLastError();
 }
 int t_red_blocks(int M) { return (M + RED_ROWS - 1) / RED_ROWS; }
+// Rows per block of the column reductions: a matrix of a few hundred rows (the FC layers: one row per candidate)
+// would otherwise be one or two blocks whose threads walk 64 rows one dependent load after the other.
+int t_colreduce_rows(int M) { return M > 16 * RED_ROWS ? RED_ROWS : 32; }
+int t_colreduce_blocks(int M) {
+    const int rows = t_colreduce_rows(M);
+    return (M + rows - 1) / rows;
+}
 
 hipError_t t_bn_stats(const float* A, int M, int C, float momentum, double* part, float* mean, float* rstd,
                       float* running_mean, float* running_var, hipStream_t s) {
-    const int nblk = t_red_blocks(M);
+    const int nblk = t_colreduce_blocks(M);
     hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, A, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, 0, part);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, 0,
+                       t_colreduce_rows(M), part);
     hipLaunchKernelGGL(k_stats_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, A, M, C, momentum, mean, rstd,
                        running_mean, running_var);
     return hipGetLastError();
 }
 hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                         float* h, int M, int C, int relu, hipStream_t s) {
-    hipLaunchKernelGGL(k_bn_act_fwd, grid1((size_t)M * C), dim3(256), 0, s, y, mean, rstd, gamma, beta, h,
-                       (size_t)M * C, C, relu);
+    if (C % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_bn_act_fwd, grid1((size_t)M * C / 4), dim3(256), 0, s, y, mean, rstd, gamma, beta, h,
+                       (size_t)M * C / 4, C, relu);
     return hipGetLastError();
 }
 // dh (in place) <- dy ; also dgamma, dbeta
 hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean, const float* rstd,
                     const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
                     float* dbeta, float* dbias_zero, hipStream_t s) {
-    const int nblk = t_red_blocks(M);
+    const int nblk = t_colreduce_blocks(M);
     hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, (const float*)dh, h, y, mean, rstd, M,
-                       C, 1, part);
+                       C, 1, t_colreduce_rows(M), part);
     hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta,
                        dbias_zero);
-    hipLaunchKernelGGL(k_bn_bwd_dense, grid1((size_t)M * C), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, m1, m2,
-                       (size_t)M * C, C);
+    hipLaunchKernelGGL(k_bn_bwd_dense, grid1((size_t)M * C / 4), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, m1, m2,
+                       (size_t)M * C / 4, C);
     return hipGetLastError();
 }
 hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s) {

@@ -84,8 +84,16 @@ struct TrainWs {
             f->mean[1] = a.take<float>(256);
             f->rstd[1] = a.take<float>(256);
         }
-        const size_t nblk = (size_t)pngpd::t_red_blocks((int)M);
-        part = a.take<double>(nblk * 2 * C3);
+        // column-reduction partials [blocks][2][C]: the per-point layers (C <= 128) and the FC layers (B rows, C <= 512);
+        // the conv1 weight gradient ([t_red_blocks][192]) and conv2's statistics records use the same buffer
+        size_t part_n = (size_t)pngpd::t_colreduce_blocks((int)M) * 2 * C2;
+        const size_t part_fc = (size_t)pngpd::t_colreduce_blocks(B) * 2 * 512;
+        const size_t part_w1 = (size_t)pngpd::t_red_blocks((int)M) * 192;
+        const size_t part_rec = (size_t)pngpd::tall_gemm_blocks((int)M) * C2 * 3;      // conv2 statistics records
+        if (part_n < part_fc) part_n = part_fc;
+        if (part_n < part_w1) part_n = part_w1;
+        if (part_n < part_rec) part_n = part_rec;
+        part = a.take<double>(part_n);
         const size_t chunks = (size_t)pngpd::t_tn_chunks((int)M);
         gram_part = a.take<double>(pngpd::t_gram_ws_doubles((int)M));
         size_t tn = chunks * (size_t)C2 * C1;       // conv2 weight-gradient partials
