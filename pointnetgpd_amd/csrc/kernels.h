@@ -161,9 +161,14 @@ struct Conv3Ws {
     float* ub;         // [128] constant row of the dense input gradient
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // optional: recorded around the product/max kernel
 };
-hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta, int B,
+// y2_pre != nullptr: h2 is an OUTPUT, relu(bn2(y2_pre)) with the given statistics and affine, written by the
+// first pass over the rows; otherwise h2 is the input.
+hipError_t t_conv3_fwd(float* h2, const float* W3, const float* b3, const float* gamma, const float* beta, int B,
                        int P, int relu_out, float momentum, double* gram_part, const Conv3Ws& w, float* mean,
-                       float* rstd, float* running_mean, float* running_var, float* pooled, int* arg, hipStream_t s);
+                       float* rstd, float* running_mean, float* running_var, float* pooled, int* arg, hipStream_t s,
+                       const float* y2_pre = nullptr, const float* bn2_mean = nullptr,
+                       const float* bn2_rstd = nullptr, const float* bn2_gamma = nullptr,
+                       const float* bn2_beta = nullptr);
 hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta,
                        const float* dpooled,
                        const float* pooled, const int* arg, const float* mean, const float* rstd, int B, int P,

@@ -157,13 +157,17 @@ int fwd_stack(StackWs& S, float* const* p, int u1, const float* x, const float* 
             HIP_TRY(pngpd::t_bn_stats(ys[l], M, ch[l], momentum, part, S.mean[l], S.rstd[l],
                                       slot(p, u, PNGPD_F_BN_MEAN), slot(p, u, PNGPD_F_BN_VAR), s));
         }
-        HIP_TRY(pngpd::t_bn_act_fwd(ys[l], S.mean[l], S.rstd[l], slot(p, u, PNGPD_F_BN_WEIGHT),
-                                    slot(p, u, PNGPD_F_BN_BIAS), hs[l], M, ch[l], 1, s));
+        // relu(bn(conv2)) is applied by the first pass of the conv3 block over these rows (t_conv3_fwd)
+        if (l == 0)
+            HIP_TRY(pngpd::t_bn_act_fwd(ys[l], S.mean[l], S.rstd[l], slot(p, u, PNGPD_F_BN_WEIGHT),
+                                        slot(p, u, PNGPD_F_BN_BIAS), hs[l], M, ch[l], 1, s));
     }
     const int u3 = u1 + 2;
     HIP_TRY(pngpd::t_conv3_fwd(S.h2, slot(p, u3, PNGPD_F_WEIGHT), slot(p, u3, PNGPD_F_BIAS), slot(p, u3, PNGPD_F_BN_WEIGHT),
                                slot(p, u3, PNGPD_F_BN_BIAS), B, P, relu_out, momentum, gram_part, S.c3, S.mean[2],
-                               S.rstd[2], slot(p, u3, PNGPD_F_BN_MEAN), slot(p, u3, PNGPD_F_BN_VAR), S.pooled, S.arg, s));
+                               S.rstd[2], slot(p, u3, PNGPD_F_BN_MEAN), slot(p, u3, PNGPD_F_BN_VAR), S.pooled, S.arg, s,
+                               S.y2, S.mean[1], S.rstd[1], slot(p, u1 + 1, PNGPD_F_BN_WEIGHT),
+                               slot(p, u1 + 1, PNGPD_F_BN_BIAS)));
     return PNGPD_OK;
 }
 

@@ -38,8 +38,26 @@ typedef __attribute__((ext_vector_type(4))) double f64x4;
 constexpr int GR_LD = 80;       // LDS row stride in floats: the 4 k rows one instruction reads fall on distinct banks
 
 // The diagonal blocks also add up the columns they load: colsum[chunk][128].
+// With bn_mean != nullptr the input is the PRE-activation y of the previous layer: the rows become
+// h = relu((y - mean)*rstd*gamma + beta) on their way into LDS (train-mode BatchNorm + ReLU of conv2,
+// model/pointnet.py:31, :145) and the diagonal blocks write them to h_out - the activation is produced by the pass
+// that first needs it instead of by a pass of its own.
+__device__ __forceinline__ float4 bn_relu4(const float4& y, const float4& mu, const float4& rs, const float4& ga,
+                                           const float4& be) {
+    float4 v;
+    v.x = fmaxf((y.x - mu.x) * rs.x * ga.x + be.x, 0.f);
+    v.y = fmaxf((y.y - mu.y) * rs.y * ga.y + be.y, 0.f);
+    v.z = fmaxf((y.z - mu.z) * rs.z * ga.z + be.z, 0.f);
+    v.w = fmaxf((y.w - mu.w) * rs.w * ga.w + be.w, 0.f);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__ A, int M, int rows_per_chunk,
-                                                       double* __restrict__ part, double* __restrict__ colsum) {
+                                                       double* __restrict__ part, double* __restrict__ colsum,
+                                                       const float* __restrict__ bn_mean,
+                                                       const float* __restrict__ bn_rstd,
+                                                       const float* __restrict__ bn_gamma,
+                                                       const float* __restrict__ bn_beta, float* __restrict__ h_out) {
     __shared__ __attribute__((aligned(16))) float sI[32 * GR_LD];
     __shared__ __attribute__((aligned(16))) float sJ[32 * GR_LD];
     __shared__ double s_cs[16][64];
@@ -56,6 +74,19 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__
         for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
     float4 va[2], vb[2];
     double cs[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool fused = bn_mean != nullptr;
+    float4 mu[2], rs[2], ga[2], be[2];          // [0]: columns i0 + lcol .., [1]: columns j0 + lcol ..
+    if (fused) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int c0 = (t == 0 ? i0 : j0) + lcol;
+            mu[t] = *(const float4*)(bn_mean + c0);
+            rs[t] = *(const float4*)(bn_rstd + c0);
+            // gamma / beta are caller tensors (a view of a flat parameter bucket need not be 16-byte aligned)
+            ga[t] = make_float4(bn_gamma[c0], bn_gamma[c0 + 1], bn_gamma[c0 + 2], bn_gamma[c0 + 3]);
+            be[t] = make_float4(bn_beta[c0], bn_beta[c0 + 1], bn_beta[c0 + 2], bn_beta[c0 + 3]);
+        }
+    }
     auto load_tile = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -65,8 +96,21 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__
             vb[i] = ok ? *(const float4*)(A + (size_t)gm * C2 + j0 + lcol) : make_float4(0, 0, 0, 0);
         }
     };
+    // BatchNorm + ReLU of the rows just loaded (rows past the end stay zero); diagonal blocks store their columns
+    auto activate = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gm = mb + lrow + 16 * i;
+            if (gm < row_end) {
+                va[i] = bn_relu4(va[i], mu[0], rs[0], ga[0], be[0]);
+                vb[i] = bn_relu4(vb[i], mu[1], rs[1], ga[1], be[1]);
+                if (i0 == j0) *(float4*)(h_out + (size_t)gm * C2 + i0 + lcol) = va[i];
+            }
+        }
+    };
     if (row_begin < row_end) load_tile(row_begin);
     for (int mb = row_begin; mb < row_end; mb += 32) {
+        if (fused) activate(mb);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -572,14 +616,20 @@ __global__ __launch_bounds__(128) void k_conv3_wgrad(const float* __restrict__ h
 // ---------------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------------
-hipError_t t_conv3_fwd(const float* h2, const float* W3, const float* b3, const float* gamma, const float* beta, int B,
+hipError_t t_conv3_fwd(float* h2, const float* W3, const float* b3, const float* gamma, const float* beta, int B,
                        int P, int relu_out, float momentum, double* gram_part, const Conv3Ws& w, float* mean, float* rstd,
-                       float* running_mean, float* running_var, float* pooled, int* arg, hipStream_t s) {
+                       float* running_mean, float* running_var, float* pooled, int* arg, hipStream_t s,
+                       const float* y2_pre, const float* bn2_mean, const float* bn2_rstd, const float* bn2_gamma,
+                       const float* bn2_beta) {
     const int M = B * P;
     hipError_t e;
     const int chunks = t_gram_chunks(M);
     double* colsum = gram_part + (size_t)chunks * C2 * C2;
-    hipLaunchKernelGGL(gram_f64_kernel, dim3(3, chunks), dim3(256), 0, s, h2, M, t_gram_rows_per_chunk(M), gram_part, colsum);
+    // y2_pre given: h2 = relu(bn2(y2_pre)) is produced by the Gram pass (and stored for the kernels after it)
+    if (y2_pre != nullptr && (!bn2_mean || !bn2_rstd || !bn2_gamma || !bn2_beta)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gram_f64_kernel, dim3(3, chunks), dim3(256), 0, s, y2_pre != nullptr ? y2_pre : (const float*)h2, M,
+                       t_gram_rows_per_chunk(M), gram_part, colsum, y2_pre != nullptr ? bn2_mean : (const float*)nullptr,
+                       bn2_rstd, bn2_gamma, bn2_beta, h2);
     hipLaunchKernelGGL(k_gram_mean, dim3(C2 / 16), dim3(256), 0, s, (const double*)colsum, chunks, M, w.abar_d);
     hipLaunchKernelGGL(k_gram_finalize, dim3(C2 * C2 / 16), dim3(256), 0, s, (const double*)gram_part, chunks,
                        (const double*)w.abar_d, M, w.cov);
