@@ -515,7 +515,6 @@ extern "C" int pngpd_debug_read_stamps(unsigned long long* stamps, unsigned long
 //      conv2 bias | per-wave running maxima.
 // ------------------------------------------------------------------------------------------
 constexpr int F32_CHUNK_BYTES = 8192;
-constexpr int F32_CHUNKS = 64;
 constexpr int F32_OFF_W2 = 2 * F32_CHUNK_BYTES;
 constexpr int F32_OFF_W1 = F32_OFF_W2 + (int)W2P_F32_BYTES;
 constexpr int F32_OFF_B2 = F32_OFF_W1 + C1 * 16;

@@ -141,7 +141,10 @@ inline int t_gram_chunks(int M) { return (M + t_gram_rows_per_chunk(M) - 1) / t_
 inline size_t t_gram_ws_doubles(int M) { return (size_t)t_gram_chunks(M) * (C2 * C2 + C2); }
 
 hipError_t t_points_to_rows(const float* x, const float* trans, float* X3, int B, int P, hipStream_t s);
-hipError_t t_conv1_fwd(const float* X3, const float* W1, const float* b1, float* y1, int M, hipStream_t s);
+int t_x3_blocks(int M);
+hipError_t t_conv1_bn_fwd(const float* X3, const float* W1, const float* b1, const float* gamma, const float* beta,
+                          float momentum, double* part, float* mean, float* rstd, float* running_mean,
+                          float* running_var, float* y1, float* h1, int M, hipStream_t s);
 hipError_t t_bn_stats(const float* A, int M, int C, float momentum, double* part, float* mean, float* rstd,
                       float* running_mean, float* running_var, hipStream_t s);
 hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,

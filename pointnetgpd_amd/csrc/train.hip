@@ -47,14 +47,86 @@ __global__ void k_points_to_rows(const float* __restrict__ x, const float* __res
     X3[(size_t)m * 3 + 2] = o2;
 }
 
-// y1[m, c] = W1[c,:] . X3[m,:] + b1[c], 64 channels; 4 rows per 256-thread block
-__global__ void k_conv1_fwd(const float* __restrict__ X3, const float* __restrict__ W1,
-                            const float* __restrict__ b1, float* __restrict__ y1, int M) {
+// ---------------------------------------------------------------------------------------------
+// conv1 + train-mode BatchNorm + ReLU in one pass over the points (model/pointnet.py:30, :143).
+// y1 = W1 x + b1 is linear in the 3 coordinates, so its batch statistics follow from the first and second
+// moments of x:  mean_c = w_c . xbar + b_c,  var_c = w_c^T Cov(x) w_c  (double) - no pass over [M,64] for them.
+// ---------------------------------------------------------------------------------------------
+constexpr int X3M_ROWS = 1024;      // rows per block of the moment sums
+
+// part[blk][9] = sums over the block's rows of x, y, z, xx, xy, xz, yy, yz, zz (double)
+__global__ __launch_bounds__(256) void k_x3_moments(const float* __restrict__ X3, int M, double* __restrict__ part) {
+    __shared__ double sh[4][9];
+    const int r0 = blockIdx.x * X3M_ROWS, r1 = min(M, r0 + X3M_ROWS);
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+        const double x = X3[(size_t)r * 3], y = X3[(size_t)r * 3 + 1], z = X3[(size_t)r * 3 + 2];
+        a[0] += x; a[1] += y; a[2] += z;
+        a[3] += x * x; a[4] += x * y; a[5] += x * z;
+        a[6] += y * y; a[7] += y * z; a[8] += z * z;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a[k] += __shfl_xor(a[k], off);
+        if (lane == 0) sh[wave][k] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 9)
+        part[(size_t)blockIdx.x * 9 + threadIdx.x] =
+            sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+// one block of 576 threads: wave k adds up moment k over the blocks (fixed order), then 64 threads finish the
+// channels: mean, rstd (biased variance, eps 1e-5) and the running update (momentum, unbiased variance)
+__global__ __launch_bounds__(576) void k_conv1_stats(const double* __restrict__ part, int nblk, int M,
+                                                     const float* __restrict__ W1, const float* __restrict__ b1,
+                                                     float momentum, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var) {
+    __shared__ double mom[9];
+    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    double a = 0.0;
+    for (int b = lane; b < nblk; b += 64) a += part[(size_t)b * 9 + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) mom[k] = a / M;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int c = threadIdx.x;
+    const double mx = mom[0], my = mom[1], mz = mom[2];
+    const double cxx = mom[3] - mx * mx, cxy = mom[4] - mx * my, cxz = mom[5] - mx * mz;
+    const double cyy = mom[6] - my * my, cyz = mom[7] - my * mz, czz = mom[8] - mz * mz;
+    const double wx = W1[3 * c], wy = W1[3 * c + 1], wz = W1[3 * c + 2];
+    const double mu = wx * mx + wy * my + wz * mz + (double)b1[c];
+    double var = wx * (cxx * wx + cxy * wy + cxz * wz) + wy * (cxy * wx + cyy * wy + cyz * wz) +
+                 wz * (cxz * wx + cyz * wy + czz * wz);
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+    if (running_mean != nullptr) {
+        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
+// y1[m, c] = W1[c,:] . X3[m,:] + b1[c] (64 channels) and h1 = relu((y1 - mean)*rstd*gamma + beta); 4 rows per 256-thread block
+__global__ __launch_bounds__(256) void k_conv1_bn_fwd(const float* __restrict__ X3, const float* __restrict__ W1,
+                                                      const float* __restrict__ b1, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y1,
+                                                      float* __restrict__ h1, int M) {
     const int c = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    const float* xr = X3 + (size_t)m * 3;
-    y1[(size_t)m * 64 + c] = W1[3 * c] * xr[0] + W1[3 * c + 1] * xr[1] + W1[3 * c + 2] * xr[2] + b1[c];
+    const float w0 = W1[3 * c], w1 = W1[3 * c + 1], w2 = W1[3 * c + 2], bb = b1[c];
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += gridDim.x * 4) {
+        const float* xr = X3 + (size_t)m * 3;
+        const float y = w0 * xr[0] + w1 * xr[1] + w2 * xr[2] + bb;
+        y1[(size_t)m * 64 + c] = y;
+        h1[(size_t)m * 64 + c] = fmaxf((y - mu) * rs * ga + be, 0.f);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,8 +636,20 @@ hipError_t t_points_to_rows(const float* x, const float* trans, float* X3, int B
     hipLaunchKernelGGL(k_points_to_rows, grid1((size_t)B * P), dim3(256), 0, s, x, trans, X3, B, P);
     return hipGetLastError();
 }
-hipError_t t_conv1_fwd(const float* X3, const float* W1, const float* b1, float* y1, int M, hipStream_t s) {
-    hipLaunchKernelGGL(k_conv1_fwd, dim3((M + 3) / 4), dim3(256), 0, s, X3, W1, b1, y1, M);
+// conv1 + BatchNorm (batch statistics from the moments of the points) + ReLU: writes y1 (kept for the backward
+// pass), h1, mean, rstd and updates the running statistics.  part: t_x3_blocks(M) * 9 doubles.
+int t_x3_blocks(int M) { return (M + X3M_ROWS - 1) / X3M_ROWS; }
+hipError_t t_conv1_bn_fwd(const float* X3, const float* W1, const float* b1, const float* gamma, const float* beta,
+                          float momentum, double* part, float* mean, float* rstd, float* running_mean,
+                          float* running_var, float* y1, float* h1, int M, hipStream_t s) {
+    const int nblk = t_x3_blocks(M);
+    hipLaunchKernelGGL(k_x3_moments, dim3(nblk), dim3(256), 0, s, X3, M, part);
+    hipLaunchKernelGGL(k_conv1_stats, dim3(1), dim3(576), 0, s, (const double*)part, nblk, M, W1, b1, momentum, mean, rstd,
+                       running_mean, running_var);
+    int blocks = (M + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_conv1_bn_fwd, dim3(blocks), dim3(256), 0, s, X3, W1, b1, (const float*)mean, (const float*)rstd,
+                       gamma, beta, y1, h1, M);
     return hipGetLastError();
 }
 int t_red_blocks(int M) { return (M + RED_ROWS - 1) / RED_ROWS; }

@@ -93,6 +93,8 @@ struct TrainWs {
         if (part_n < part_fc) part_n = part_fc;
         if (part_n < part_w1) part_n = part_w1;
         if (part_n < part_rec) part_n = part_rec;
+        const size_t part_x3 = (size_t)pngpd::t_x3_blocks((int)M) * 9;                   // moments of the points
+        if (part_n < part_x3) part_n = part_x3;
         part = a.take<double>(part_n);
         const size_t chunks = (size_t)pngpd::t_tn_chunks((int)M);
         gram_part = a.take<double>(pngpd::t_gram_ws_doubles((int)M));
@@ -140,28 +142,17 @@ int check_shape(int B, int P, int k, const void* ws, size_t ws_bytes) {
 int fwd_stack(StackWs& S, float* const* p, int u1, const float* x, const float* trans, int B, int P, int relu_out,
               float momentum, double* part, double* gram_part, hipStream_t s) {
     const int M = B * P;
-    const int ch[2] = {C1, C2};
-    float* ys[2] = {S.y1, S.y2};
-    float* hs[2] = {S.h1, S.h2};
     HIP_TRY(pngpd::t_points_to_rows(x, trans, S.X3, B, P, s));
-    HIP_TRY(pngpd::t_conv1_fwd(S.X3, slot(p, u1, PNGPD_F_WEIGHT), slot(p, u1, PNGPD_F_BIAS), S.y1, M, s));
-    for (int l = 0; l < 2; ++l) {
-        const int u = u1 + l;
-        if (l > 0) {
-            // conv2 with the column statistics of its output taken from the accumulators
-            HIP_TRY(pngpd::launch_tall_gemm(hs[l - 1], slot(p, u, PNGPD_F_WEIGHT), 0, slot(p, u, PNGPD_F_BIAS), ys[l], M,
-                                            ch[l], ch[l - 1], 0, part, s));
-            HIP_TRY(pngpd::t_stats_from_records(part, pngpd::tall_gemm_blocks(M), M, ch[l], momentum, S.mean[l],
-                                                S.rstd[l], slot(p, u, PNGPD_F_BN_MEAN), slot(p, u, PNGPD_F_BN_VAR), s));
-        } else {
-            HIP_TRY(pngpd::t_bn_stats(ys[l], M, ch[l], momentum, part, S.mean[l], S.rstd[l],
-                                      slot(p, u, PNGPD_F_BN_MEAN), slot(p, u, PNGPD_F_BN_VAR), s));
-        }
-        // relu(bn(conv2)) is applied by the first pass of the conv3 block over these rows (t_conv3_fwd)
-        if (l == 0)
-            HIP_TRY(pngpd::t_bn_act_fwd(ys[l], S.mean[l], S.rstd[l], slot(p, u, PNGPD_F_BN_WEIGHT),
-                                        slot(p, u, PNGPD_F_BN_BIAS), hs[l], M, ch[l], 1, s));
-    }
+    // conv1 + bn1 + relu: statistics from the moments of the points, one pass that writes y1 and h1
+    HIP_TRY(pngpd::t_conv1_bn_fwd(S.X3, slot(p, u1, PNGPD_F_WEIGHT), slot(p, u1, PNGPD_F_BIAS),
+                                  slot(p, u1, PNGPD_F_BN_WEIGHT), slot(p, u1, PNGPD_F_BN_BIAS), momentum, part, S.mean[0],
+                                  S.rstd[0], slot(p, u1, PNGPD_F_BN_MEAN), slot(p, u1, PNGPD_F_BN_VAR), S.y1, S.h1, M, s));
+    // conv2 with the column statistics of its output taken from the accumulators; relu(bn(conv2)) is applied by
+    // the first pass of the conv3 block over these rows (t_conv3_fwd)
+    HIP_TRY(pngpd::launch_tall_gemm(S.h1, slot(p, u1 + 1, PNGPD_F_WEIGHT), 0, slot(p, u1 + 1, PNGPD_F_BIAS), S.y2, M, C2,
+                                    C1, 0, part, s));
+    HIP_TRY(pngpd::t_stats_from_records(part, pngpd::tall_gemm_blocks(M), M, C2, momentum, S.mean[1], S.rstd[1],
+                                        slot(p, u1 + 1, PNGPD_F_BN_MEAN), slot(p, u1 + 1, PNGPD_F_BN_VAR), s));
     const int u3 = u1 + 2;
     HIP_TRY(pngpd::t_conv3_fwd(S.h2, slot(p, u3, PNGPD_F_WEIGHT), slot(p, u3, PNGPD_F_BIAS), slot(p, u3, PNGPD_F_BN_WEIGHT),
                                slot(p, u3, PNGPD_F_BN_BIAS), B, P, relu_out, momentum, gram_part, S.c3, S.mean[2],
