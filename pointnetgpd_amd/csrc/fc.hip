@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void fc_f32_kernel(const float* __restrict__ X
                                                      const float* __restrict__ W,
                                                      const float* __restrict__ bias,
                                                      float* __restrict__ Y, int M, int N, int K,
-                                                     int relu) {
+                                                     int relu, float* __restrict__ part) {
     __shared__ float sA[FC_BM * FC_LD];
     __shared__ float sB[FC_BN * FC_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -44,8 +44,10 @@ __global__ __launch_bounds__(256) void fc_f32_kernel(const float* __restrict__ X
             vb[i] = *(const float4*)(W + (size_t)(n0 + row) * K + k0 + lcol);
         }
     };
-    load_tile(0);
-    for (int k0 = 0; k0 < K; k0 += FC_BK) {
+    // split K: slice blockIdx.z of gridDim.z covers k in [k_begin, k_end) and writes a partial product
+    const int k_len = K / (int)gridDim.z, k_begin = (int)blockIdx.z * k_len, k_end = k_begin + k_len;
+    load_tile(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += FC_BK) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void fc_f32_kernel(const float* __restrict__ X
             pb[0] = vb[i].x; pb[1] = vb[i].y; pb[2] = vb[i].z; pb[3] = vb[i].w;
         }
         __syncthreads();
-        if (k0 + FC_BK < K) load_tile(k0 + FC_BK);     // in flight during this tile's MFMAs
+        if (k0 + FC_BK < k_end) load_tile(k0 + FC_BK);     // in flight during this tile's MFMAs
         const float* ra = sA + (wm * 32 + r) * FC_LD + h;
         const float* rb = sB + (wn * 32 + r) * FC_LD + h;
 #pragma unroll
@@ -63,6 +65,15 @@ __global__ __launch_bounds__(256) void fc_f32_kernel(const float* __restrict__ X
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[2 * s], rb[2 * s], acc, 0, 0, 0);
     }
     const int col = n0 + wn * 32 + r;
+    if (part != nullptr) {          // bias and activation are applied by splitk_reduce_kernel
+        float* dst = part + (size_t)blockIdx.z * M * N;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (row < M) dst[(size_t)row * N + col] = acc[i];
+        }
+        return;
+    }
     const float bv = bias[col];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -73,6 +84,28 @@ __global__ __launch_bounds__(256) void fc_f32_kernel(const float* __restrict__ X
             Y[(size_t)row * N + col] = v;
         }
     }
+}
+
+// out[i] = act(sum_z part[z][i] + bias[i % N]): the slices are added in a fixed order (reproducible)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ks, size_t n4, int N,
+                                                            const float* __restrict__ bias, int relu,
+                                                            float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = ((const float4*)part)[i];
+    for (int z = 1; z < ks; ++z) {
+        const float4 b = ((const float4*)part)[(size_t)z * n4 + i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (bias != nullptr) {
+        const int c = (int)((i * 4) % (size_t)N);
+        a.x += bias[c]; a.y += bias[c + 1]; a.z += bias[c + 2]; a.w += bias[c + 3];
+    }
+    if (relu) {
+        a.x = __builtin_fmaxf(a.x, 0.f); a.y = __builtin_fmaxf(a.y, 0.f);
+        a.z = __builtin_fmaxf(a.z, 0.f); a.w = __builtin_fmaxf(a.w, 0.f);
+    }
+    ((float4*)out)[i] = a;
 }
 
 // One wave per tile of 16 rows on v_mfma_f32_16x16x4_f32 (A[row = l&15][k = l>>4], B[k = l>>4][col = l&15],
@@ -148,8 +181,39 @@ hipError_t launch_fc_f32(const float* X, const float* W, const float* b, float* 
                          int K, int relu, hipStream_t s) {
     if (!X || !W || !b || !Y || M < 1 || N % FC_BN != 0 || K % FC_BK != 0) return hipErrorInvalidValue;
     dim3 grid(N / FC_BN, (M + FC_BM - 1) / FC_BM);
-    hipLaunchKernelGGL(fc_f32_kernel, grid, dim3(256), 0, s, X, W, b, Y, M, N, K, relu);
+    hipLaunchKernelGGL(fc_f32_kernel, grid, dim3(256), 0, s, X, W, b, Y, M, N, K, relu, (float*)nullptr);
     return hipGetLastError();
+}
+
+// A product of a few hundred rows has only a few dozen 64x64 output tiles: the k range is then cut into slices,
+// one workgroup each, until the grid covers the chip (a tile's k loop is a chain of dependent MFMAs).
+int splitk_factor(int tiles, int k_tiles) {
+    int ks = 1;
+    while (tiles * ks * 2 <= SPLITK_MAX_WORKGROUPS && k_tiles % (ks * 2) == 0 && k_tiles / (ks * 2) >= 2) ks *= 2;
+    return ks;
+}
+
+hipError_t launch_splitk_reduce(const float* part, int ks, int M, int N, const float* bias, int relu, float* out,
+                                hipStream_t s) {
+    if (!part || !out || ks < 1 || M < 1 || N % 4 != 0) return hipErrorInvalidValue;
+    const size_t n4 = (size_t)M * N / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, ks, n4, N, bias,
+                       relu, out);
+    return hipGetLastError();
+}
+
+// launch_fc_f32 for small M: split over k into `part` (SPLITK_PART_FLOATS floats), then reduced into Y
+hipError_t launch_fc_f32_splitk(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int relu,
+                                float* part, hipStream_t s) {
+    if (!X || !W || !b || !Y || !part || M < 1 || N % FC_BN != 0 || K % FC_BK != 0) return hipErrorInvalidValue;
+    dim3 grid(N / FC_BN, (M + FC_BM - 1) / FC_BM);
+    const int ks = splitk_factor((int)(grid.x * grid.y), K / FC_BK);
+    if (ks == 1 || (size_t)ks * M * N > SPLITK_PART_FLOATS) return launch_fc_f32(X, W, b, Y, M, N, K, relu, s);
+    grid.z = ks;
+    hipLaunchKernelGGL(fc_f32_kernel, grid, dim3(256), 0, s, X, W, b, Y, M, N, K, relu, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_splitk_reduce(part, ks, M, N, b, relu, Y, s);
 }
 
 hipError_t launch_fc_tail(const float* X, const float* W, const float* b, float* Y, int M, int N,

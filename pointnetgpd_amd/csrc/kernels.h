@@ -45,6 +45,15 @@ hipError_t launch_conv_stack_bf16(const ConvStackArgs& a, hipStream_t s);
 hipError_t launch_conv_stack_f32(const ConvStackArgs& a, hipStream_t s);
 
 // Y[M,N] = act(X[M,K] * W[N,K]^T + b[N]); fp32 MFMA.  N % 64 == 0, K % 32 == 0.
+// split-k products of the training step's FC layers (few rows): slices * tiles <= SPLITK_MAX_WORKGROUPS, so the
+// partial products never exceed SPLITK_MAX_WORKGROUPS 64x64 tiles
+constexpr int SPLITK_MAX_WORKGROUPS = 256;
+constexpr size_t SPLITK_PART_FLOATS = (size_t)SPLITK_MAX_WORKGROUPS * 64 * 64;
+int splitk_factor(int tiles, int k_tiles);
+hipError_t launch_splitk_reduce(const float* part, int ks, int M, int N, const float* bias, int relu, float* out,
+                                hipStream_t s);
+hipError_t launch_fc_f32_splitk(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int relu,
+                                float* part, hipStream_t s);
 hipError_t launch_fc_f32(const float* X, const float* W, const float* b, float* Y, int M, int N,
                          int K, int relu, hipStream_t s);
 
@@ -177,7 +186,8 @@ hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const 
                        const float* pooled, const int* arg, const float* mean, const float* rstd, int B, int P,
                        int relu_out, const Conv3Ws& w, float* m1, float* m2, float* dW3, float* db3_zero, float* dgamma,
                        float* dbeta, float* dh2, hipStream_t s);
-hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s);
+hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s,
+                     float* splitk_part = nullptr);
 hipError_t t_gemm_tn(const float* dY, const float* Hm, float* part, float* dW, int M, int N, int K, hipStream_t s);
 hipError_t t_conv1_bwd(const float* dy1, const float* X3, const float* W1, int M, double* part, float* dW1,
                        float* dX3, hipStream_t s);

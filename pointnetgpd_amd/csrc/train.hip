@@ -333,7 +333,8 @@ constexpr int GB_M = 64, GB_N = 64, GB_K = 32;
 // dX[M,Kout] = dY[M,N] W[N,Kout];  Kout % 64 == 0, N % 32 == 0.
 // optional fused mask: dX *= (Hmask > 0) is NOT applied here (BN backward needs the unmasked sums).
 __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ dY, const float* __restrict__ W,
-                                                      float* __restrict__ dX, int M, int N, int Kout) {
+                                                      float* __restrict__ dX, int M, int N, int Kout,
+                                                      float* __restrict__ part) {
     __shared__ float sA[GB_M * (GB_K + 1)];
     __shared__ float sB[GB_K * GB_N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -351,8 +352,10 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
             vb[i] = *(const float4*)(W + (size_t)(n0 + brow + 16 * i) * Kout + k0 + bcol);
         }
     };
-    load_tile(0);
-    for (int n0 = 0; n0 < N; n0 += GB_K) {
+    // split over the summed dimension: slice blockIdx.z of gridDim.z writes a partial product (launch_splitk_reduce)
+    const int n_len = N / (int)gridDim.z, n_begin = (int)blockIdx.z * n_len, n_end = n_begin + n_len;
+    load_tile(n_begin);
+    for (int n0 = n_begin; n0 < n_end; n0 += GB_K) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
             *(float4*)(sB + (brow + 16 * i) * GB_N + bcol) = vb[i];
         }
         __syncthreads();
-        if (n0 + GB_K < N) load_tile(n0 + GB_K);       // in flight during this tile's MFMAs
+        if (n0 + GB_K < n_end) load_tile(n0 + GB_K);       // in flight during this tile's MFMAs
         const float* ra = sA + (wm * 32 + r) * (GB_K + 1) + h;
         const float* rb = sB + h * GB_N + wn * 32 + r;
 #pragma unroll
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (row < M) dX[(size_t)row * Kout + col] = acc[i];
+        if (row < M) (part != nullptr ? part + (size_t)blockIdx.z * M * Kout : dX)[(size_t)row * Kout + col] = acc[i];
     }
 }
 
@@ -691,10 +694,17 @@ hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean
                        (size_t)M * C / 4, C);
     return hipGetLastError();
 }
-hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s) {
+hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s,
+                     float* splitk_part) {
     if (Kout % 64 != 0 || N % 32 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gemm_nn_kernel, dim3(Kout / 64, (M + 63) / 64), dim3(256), 0, s, dY, W, dX, M, N, Kout);
-    return hipGetLastError();
+    dim3 grid(Kout / 64, (M + 63) / 64);
+    int ks = splitk_part != nullptr ? splitk_factor((int)(grid.x * grid.y), N / GB_K) : 1;
+    if ((size_t)ks * M * Kout > SPLITK_PART_FLOATS) ks = 1;
+    grid.z = ks;
+    hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(256), 0, s, dY, W, dX, M, N, Kout, ks > 1 ? splitk_part : (float*)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ks == 1) return e;
+    return launch_splitk_reduce(splitk_part, ks, M, Kout, nullptr, 0, dX, s);
 }
 int t_tn_chunks(int M) { return (M + TN_ROWS_PER_CHUNK - 1) / TN_ROWS_PER_CHUNK; }
 

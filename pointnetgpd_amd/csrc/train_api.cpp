@@ -41,7 +41,7 @@ struct TrainWs {
     FcWs stn_fc, head_fc;
     double* part;
     double* gram_part;
-    float *tn_part, *m1, *m2, *dlogits, *dtrans, *trans;
+    float *tn_part, *fc_part, *m1, *m2, *dlogits, *dtrans, *trans;
     size_t bytes;
 
     TrainWs(void* base, int B, int P, int k) {
@@ -101,6 +101,7 @@ struct TrainWs {
         size_t tn = chunks * (size_t)C2 * C1;       // conv2 weight-gradient partials
         if (tn < (size_t)512 * 1024) tn = (size_t)512 * 1024;
         tn_part = a.take<float>(tn);
+        fc_part = a.take<float>(pngpd::SPLITK_PART_FLOATS);      // split-k partial products of the FC layers
         m1 = a.take<float>(C3);
         m2 = a.take<float>(C3);
         dlogits = a.take<float>((size_t)B * 16);
@@ -164,15 +165,15 @@ int fwd_stack(StackWs& S, float* const* p, int u1, const float* x, const float* 
 
 // linear -> bn -> relu -> linear -> bn -> relu -> linear (+ identity | log_softmax)
 int fwd_fc(FcWs& F, float* const* p, int u1, const float* in, float* out, int B, int n_last, int tail, float momentum,
-           double* part, hipStream_t s) {
+           double* part, float* fc_part, hipStream_t s) {
     const int n[2] = {512, 256}, kk[2] = {1024, 512};
     float* zs[2] = {F.z1, F.z2};
     float* as[2] = {F.a1, F.a2};
     const float* cur = in;
     for (int l = 0; l < 2; ++l) {
         const int u = u1 + l;
-        HIP_TRY(pngpd::launch_fc_f32(cur, slot(p, u, PNGPD_F_WEIGHT), slot(p, u, PNGPD_F_BIAS), zs[l], B, n[l], kk[l],
-                                     0, s));
+        HIP_TRY(pngpd::launch_fc_f32_splitk(cur, slot(p, u, PNGPD_F_WEIGHT), slot(p, u, PNGPD_F_BIAS), zs[l], B, n[l],
+                                            kk[l], 0, fc_part, s));
         HIP_TRY(pngpd::t_bn_stats(zs[l], B, n[l], momentum, part, F.mean[l], F.rstd[l], slot(p, u, PNGPD_F_BN_MEAN),
                                   slot(p, u, PNGPD_F_BN_VAR), s));
         HIP_TRY(pngpd::t_bn_act_fwd(zs[l], F.mean[l], F.rstd[l], slot(p, u, PNGPD_F_BN_WEIGHT),
@@ -194,13 +195,13 @@ int bwd_fc(FcWs& F, const float* const* p, float* const* g, int u1, const float*
                             W.part, W.m1, W.m2, slot(g, u1 + 1, PNGPD_F_BN_WEIGHT), slot(g, u1 + 1, PNGPD_F_BN_BIAS),
                             slot(g, u1 + 1, PNGPD_F_BIAS), s));
     HIP_TRY(pngpd::t_gemm_tn(F.da2, F.a1, W.tn_part, slot(g, u1 + 1, PNGPD_F_WEIGHT), B, 256, 512, s));
-    HIP_TRY(pngpd::t_gemm_nn(F.da2, cslot(p, u1 + 1, PNGPD_F_WEIGHT), F.da1, B, 256, 512, s));
+    HIP_TRY(pngpd::t_gemm_nn(F.da2, cslot(p, u1 + 1, PNGPD_F_WEIGHT), F.da1, B, 256, 512, s, W.fc_part));
     // layer 1
     HIP_TRY(pngpd::t_bn_bwd(F.da1, F.a1, F.z1, F.mean[0], F.rstd[0], cslot(p, u1, PNGPD_F_BN_WEIGHT), B, 512, W.part,
                             W.m1, W.m2, slot(g, u1, PNGPD_F_BN_WEIGHT), slot(g, u1, PNGPD_F_BN_BIAS),
                             slot(g, u1, PNGPD_F_BIAS), s));
     HIP_TRY(pngpd::t_gemm_tn(F.da1, in, W.tn_part, slot(g, u1, PNGPD_F_WEIGHT), B, 512, 1024, s));
-    HIP_TRY(pngpd::t_gemm_nn(F.da1, cslot(p, u1, PNGPD_F_WEIGHT), F.din, B, 512, 1024, s));
+    HIP_TRY(pngpd::t_gemm_nn(F.da1, cslot(p, u1, PNGPD_F_WEIGHT), F.din, B, 512, 1024, s, W.fc_part));
     return PNGPD_OK;
 }
 
@@ -258,13 +259,13 @@ static int train_forward_impl(int B, int P, int k, const float* x_dev, float* co
     if ((rc = fwd_stack(W.stn, params_dev, PNGPD_U_STN_CONV1, x_dev, nullptr, B, P, 1, momentum, W.part, W.gram_part, s)))
         return rc;
     if ((rc = fwd_fc(W.stn_fc, params_dev, PNGPD_U_STN_FC1, W.stn.pooled, trans, B, 9, pngpd::FC_TAIL_ADD_IDENTITY,
-                     momentum, W.part, s)))
+                     momentum, W.part, W.fc_part, s)))
         return rc;
     if ((rc = fwd_stack(W.trunk, params_dev, PNGPD_U_FEAT_CONV1, x_dev, trans, B, P, 0, momentum, W.part, W.gram_part,
                        s)))
         return rc;
     if ((rc = fwd_fc(W.head_fc, params_dev, PNGPD_U_FC1, W.trunk.pooled, logp_dev, B, k, pngpd::FC_TAIL_LOG_SOFTMAX,
-                     momentum, W.part, s)))
+                     momentum, W.part, W.fc_part, s)))
         return rc;
     if (feat_dev)
         HIP_TRY(hipMemcpyAsync(feat_dev, W.trunk.pooled, (size_t)B * C3 * sizeof(float), hipMemcpyDeviceToDevice, s));
