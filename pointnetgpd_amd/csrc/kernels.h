@@ -154,6 +154,9 @@ int t_x3_blocks(int M);
 hipError_t t_conv1_bn_fwd(const float* X3, const float* W1, const float* b1, const float* gamma, const float* beta,
                           float momentum, double* part, float* mean, float* rstd, float* running_mean,
                           float* running_var, float* y1, float* h1, int M, hipStream_t s);
+hipError_t t_fc_bn_fwd(const float* X, const float* W, const float* b, const float* gamma, const float* beta, int M,
+                       int N, int K, float momentum, double* part, float* splitk_part, float* Z, float* A, float* mean,
+                       float* rstd, float* running_mean, float* running_var, hipStream_t s);
 hipError_t t_bn_stats(const float* A, int M, int C, float momentum, double* part, float* mean, float* rstd,
                       float* running_mean, float* running_var, hipStream_t s);
 hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,

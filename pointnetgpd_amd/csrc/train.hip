@@ -269,6 +269,114 @@ __global__ __launch_bounds__(256) void k_bnbwd_finalize(const double* __restrict
     if (dbias_zero != nullptr) dbias_zero[c] = 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// BatchNorm of a matrix of few rows (the FC layers: one row per candidate) in ONE kernel per direction.
+// A workgroup owns 16 columns and all M rows (16 row lanes), so the column sums stay inside it: no partial
+// buffers, no finalize kernel, no separate normalisation pass - at this size each of those was a launch of its own
+// that cost more than its work.  Sums in double, added in a fixed order.
+// ---------------------------------------------------------------------------------------------
+constexpr int FEW_ROWS_MAX = 1024;
+
+__device__ __forceinline__ double few_rows_colsum(double v, double (*sh)[16], int cl, int rl) {
+    __syncthreads();
+    sh[rl][cl] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += sh[k][cl];
+    return t;
+}
+
+// forward: batch statistics of z, a = relu((z - mean)*rstd*gamma + beta); writes a, mean, rstd and the running
+// update.  RPT rows per thread (M <= 16*RPT) live in registers: every load is issued before the first use.
+template <int RPT>
+__global__ __launch_bounds__(256) void k_few_rows_bn_fwd(const float* __restrict__ z, int M, int C,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float momentum,
+                                                         float* __restrict__ a, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var) {
+    __shared__ double sh[16][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float v[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int r = rl + 16 * j;
+        v[j] = r < M ? z[(size_t)r * C + c] : 0.f;
+    }
+    double s1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j)
+        if (rl + 16 * j < M) s1 += (double)v[j];
+    const double mu = few_rows_colsum(s1, sh, cl, rl) / M;
+    double s2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j)
+        if (rl + 16 * j < M) {
+            const double d = (double)v[j] - mu;
+            s2 += d * d;
+        }
+    const double var = few_rows_colsum(s2, sh, cl, rl) / M;
+    const float mf = (float)mu, rs = (float)(1.0 / sqrt(var + (double)BN_EPS));
+    const float ga = gamma[c], be = beta[c];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int r = rl + 16 * j;
+        if (r < M) a[(size_t)r * C + c] = fmaxf((v[j] - mf) * rs * ga + be, 0.f);
+    }
+    if (rl != 0) return;
+    mean[c] = mf;
+    rstd[c] = rs;
+    if (running_mean != nullptr) {
+        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
+// backward, in place over dh: g = dh*(h > 0), dh <- gamma*rstd*(g - mean(g) - yhat*mean(g*yhat)); dgamma, dbeta,
+// and the exact 0 of the bias in front of the BatchNorm
+template <int RPT>
+__global__ __launch_bounds__(256) void k_few_rows_bn_bwd(float* __restrict__ dh, const float* __restrict__ h,
+                                                         const float* __restrict__ y, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, int M, int C,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         float* __restrict__ dbias_zero) {
+    __shared__ double sh[16][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const float mu = mean[c], rs = rstd[c];
+    float g[RPT], yh[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int r = rl + 16 * j;
+        const size_t i = (size_t)(r < M ? r : 0) * C + c;
+        const float gv = dh[i], hv = h[i], yv = y[i];
+        g[j] = (r < M && hv > 0.f) ? gv : 0.f;
+        yh[j] = (yv - mu) * rs;
+    }
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j)
+        if (rl + 16 * j < M) {
+            s1 += (double)g[j];
+            s2 += (double)(g[j] * yh[j]);
+        }
+    s1 = few_rows_colsum(s1, sh, cl, rl);
+    s2 = few_rows_colsum(s2, sh, cl, rl);
+    const float m1 = (float)(s1 / M), m2 = (float)(s2 / M), gr = gamma[c] * rs;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int r = rl + 16 * j;
+        if (r < M) dh[(size_t)r * C + c] = gr * (g[j] - m1 - yh[j] * m2);
+    }
+    if (rl != 0) return;
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+    if (dbias_zero != nullptr) dbias_zero[c] = 0.f;
+}
+
 // h = relu((y - mean)*rstd*gamma + beta)   (relu optional); four consecutive channels per thread (C % 4 == 0)
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ y, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -674,6 +782,29 @@ hipError_t t_bn_stats(const float* A, int M, int C, float momentum, double* part
                        running_mean, running_var);
     return hipGetLastError();
 }
+// FC layer forward in training: Z = X W^T + b, batch statistics, A = relu(bn(Z)).  Few rows: split-k product (with
+// its reduce) and one kernel for the rest; otherwise product, column reduction, finalize, normalisation.
+hipError_t t_fc_bn_fwd(const float* X, const float* W, const float* b, const float* gamma, const float* beta, int M,
+                       int N, int K, float momentum, double* part, float* splitk_part, float* Z, float* A, float* mean,
+                       float* rstd, float* running_mean, float* running_var, hipStream_t s) {
+    hipError_t e;
+    if (M <= FEW_ROWS_MAX && N % 64 == 0 && splitk_part != nullptr) {
+        e = launch_fc_f32_splitk(X, W, b, Z, M, N, K, 0, splitk_part, s);
+        if (e != hipSuccess) return e;
+        if (M <= 256)
+            hipLaunchKernelGGL(k_few_rows_bn_fwd<16>, dim3(N / 16), dim3(256), 0, s, (const float*)Z, M, N, gamma, beta,
+                               momentum, A, mean, rstd, running_mean, running_var);
+        else
+            hipLaunchKernelGGL(k_few_rows_bn_fwd<FEW_ROWS_MAX / 16>, dim3(N / 16), dim3(256), 0, s, (const float*)Z, M, N,
+                               gamma, beta, momentum, A, mean, rstd, running_mean, running_var);
+        return hipGetLastError();
+    }
+    e = launch_fc_f32(X, W, b, Z, M, N, K, 0, s);
+    if (e != hipSuccess) return e;
+    e = t_bn_stats(Z, M, N, momentum, part, mean, rstd, running_mean, running_var, s);
+    if (e != hipSuccess) return e;
+    return t_bn_act_fwd(Z, mean, rstd, gamma, beta, A, M, N, 1, s);
+}
 hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                         float* h, int M, int C, int relu, hipStream_t s) {
     if (C % 4 != 0) return hipErrorInvalidValue;
@@ -685,6 +816,15 @@ hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, co
 hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean, const float* rstd,
                     const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
                     float* dbeta, float* dbias_zero, hipStream_t s) {
+    if (M <= FEW_ROWS_MAX && C % 16 == 0 && h != nullptr) {
+        if (M <= 256)
+            hipLaunchKernelGGL(k_few_rows_bn_bwd<16>, dim3(C / 16), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, M, C,
+                               dgamma, dbeta, dbias_zero);
+        else
+            hipLaunchKernelGGL(k_few_rows_bn_bwd<FEW_ROWS_MAX / 16>, dim3(C / 16), dim3(256), 0, s, dh, h, y, mean, rstd,
+                               gamma, M, C, dgamma, dbeta, dbias_zero);
+        return hipGetLastError();
+    }
     const int nblk = t_colreduce_blocks(M);
     hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, (const float*)dh, h, y, mean, rstd, M,
                        C, 1, t_colreduce_rows(M), part);

@@ -172,12 +172,9 @@ int fwd_fc(FcWs& F, float* const* p, int u1, const float* in, float* out, int B,
     const float* cur = in;
     for (int l = 0; l < 2; ++l) {
         const int u = u1 + l;
-        HIP_TRY(pngpd::launch_fc_f32_splitk(cur, slot(p, u, PNGPD_F_WEIGHT), slot(p, u, PNGPD_F_BIAS), zs[l], B, n[l],
-                                            kk[l], 0, fc_part, s));
-        HIP_TRY(pngpd::t_bn_stats(zs[l], B, n[l], momentum, part, F.mean[l], F.rstd[l], slot(p, u, PNGPD_F_BN_MEAN),
-                                  slot(p, u, PNGPD_F_BN_VAR), s));
-        HIP_TRY(pngpd::t_bn_act_fwd(zs[l], F.mean[l], F.rstd[l], slot(p, u, PNGPD_F_BN_WEIGHT),
-                                    slot(p, u, PNGPD_F_BN_BIAS), as[l], B, n[l], 1, s));
+        HIP_TRY(pngpd::t_fc_bn_fwd(cur, slot(p, u, PNGPD_F_WEIGHT), slot(p, u, PNGPD_F_BIAS), slot(p, u, PNGPD_F_BN_WEIGHT),
+                                   slot(p, u, PNGPD_F_BN_BIAS), B, n[l], kk[l], momentum, part, fc_part, zs[l], as[l],
+                                   F.mean[l], F.rstd[l], slot(p, u, PNGPD_F_BN_MEAN), slot(p, u, PNGPD_F_BN_VAR), s));
         cur = as[l];
     }
     HIP_TRY(pngpd::launch_fc_tail(F.a2, slot(p, u1 + 2, PNGPD_F_WEIGHT), slot(p, u1 + 2, PNGPD_F_BIAS), out, B, n_last,

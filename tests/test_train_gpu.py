@@ -141,7 +141,10 @@ def test_fused_trainer_matches_autograd_path_and_oracle():
     loss_ref, ref_sd, grads = oracle_step(sd1, hip_moments())
     loss = tr.step(x.cuda(), target.cuda())[0].item()
     assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
-    compare(ref_sd, grads, 5e-5)
+    # BatchNorm over these 6 samples amplifies float32 rounding: two correct float32 forward passes whose FC
+    # activations both sit within 1e-5 of a float64 evaluation give gradients that differ by up to 3e-4 of their
+    # largest entry (tests/diag_trainer_step2.py prints them per parameter), i.e. a few 1e-4 after Adam's scaling
+    compare(ref_sd, grads, 2e-4)
     # eval after training must re-fold / re-pack the weights the fused update wrote: compare with the
     # oracle evaluated on the HIP model's OWN post-training state_dict
     m.eval()
