@@ -10,3 +10,5 @@ run b64 --batch 64 --no-cpu-baseline
 run train --workload train
 run online --workload online
 run voxel --workload voxel
+timeout -k 10 300 python -c "import sys; sys.path.insert(0, '$R'); import __graft_entry__ as g; g.smoke()" > $O/final_smoke.log 2>&1 || { tail -20 $O/final_smoke.log; exit 1; }
+tail -2 $O/final_smoke.log
