@@ -36,7 +36,8 @@ enum {
     PNGPD_ERR_WORKSPACE = 5  /* workspace smaller than pngpd_*_workspace_bytes()     */
 };
 
-/* arithmetic of the two fused conv stacks (FC layers are always fp32) */
+/* arithmetic of the two fused conv stacks: exact-f32 MFMA, or bf16 operands with f32 accumulation.  The FC layers
+ * give f32-grade results in both modes (f32 MFMA; split-bf16 products, hi + lo operands, in BF16 mode). */
 enum { PNGPD_FP32 = 0, PNGPD_BF16 = 1 };
 
 /* memory layout of the candidate points */
