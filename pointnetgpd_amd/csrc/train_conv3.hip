@@ -451,14 +451,16 @@ __global__ __launch_bounds__(256) void k_conv3_bwd_reduce(const float* __restric
 }
 
 // G[i][k] = sum_c q_c W[c,i] W[c,k] (blocks 0..127 = i), ub[k] = sum_c (p_c - q_c (mean_c - b_c)) W[c,k] (block 128)
-__global__ __launch_bounds__(128) void k_conv3_bwd_G(const float* __restrict__ W3, const float* __restrict__ b3,
+// 512 threads = 128 columns k x 4 groups of 256 channels; the group sums are added in a fixed order.
+__global__ __launch_bounds__(512) void k_conv3_bwd_G(const float* __restrict__ W3, const float* __restrict__ b3,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ m1,
                                                      const float* __restrict__ m2, float* __restrict__ G,
                                                      float* __restrict__ ub) {
     __shared__ double s_f[C3];
-    const int i = blockIdx.x, k = threadIdx.x;
-    for (int c = k; c < C3; c += 128) {
+    __shared__ double s_acc[4][C2];
+    const int i = blockIdx.x, k = threadIdx.x & (C2 - 1), cg = threadIdx.x >> 7;
+    for (int c = threadIdx.x; c < C3; c += 512) {
         const double A = (double)gamma[c] * (double)rstd[c];
         const double q = -A * (double)rstd[c] * (double)m2[c];
         if (i < C2)
@@ -468,8 +470,13 @@ __global__ __launch_bounds__(128) void k_conv3_bwd_G(const float* __restrict__ W
     }
     __syncthreads();
     double acc = 0.0;
+    const int c0 = cg * (C3 / 4);
 #pragma unroll 8
-    for (int c = 0; c < C3; ++c) acc += s_f[c] * (double)W3[(size_t)c * C2 + k];
+    for (int c = c0; c < c0 + C3 / 4; ++c) acc += s_f[c] * (double)W3[(size_t)c * C2 + k];
+    s_acc[cg][k] = acc;
+    __syncthreads();
+    if (cg != 0) return;
+    acc = s_acc[0][k] + s_acc[1][k] + s_acc[2][k] + s_acc[3][k];
     if (i < C2)
         G[(size_t)i * C2 + k] = (float)acc;
     else
@@ -663,7 +670,7 @@ hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const 
     const int M = B * P;
     hipLaunchKernelGGL(k_conv3_bwd_reduce, dim3(C3 / 16), dim3(256), 0, s, h2, W3, b3, gamma, beta, mean, rstd, dpooled,
                        pooled, arg, B, P, relu_out, w.gmask, m1, m2, dgamma, dbeta, db3_zero);
-    hipLaunchKernelGGL(k_conv3_bwd_G, dim3(C2 + 1), dim3(128), 0, s, W3, b3, gamma, mean, rstd, (const float*)m1,
+    hipLaunchKernelGGL(k_conv3_bwd_G, dim3(C2 + 1), dim3(512), 0, s, W3, b3, gamma, mean, rstd, (const float*)m1,
                        (const float*)m2, w.G, w.ub);
     hipError_t e = launch_tall_gemm(h2, w.G, 1, w.ub, dh2, M, C2, C2, 0, nullptr, s);
     if (e != hipSuccess) return e;
