@@ -565,6 +565,7 @@ __global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ d
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int r0 = blockIdx.x * RED_ROWS, r1 = min(M, r0 + RED_ROWS);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
     for (int r = r0 + rl; r < r1; r += 4) {
         const float g = dy1[(size_t)r * 64 + cl];
         s0 += g * X3[(size_t)r * 3 + 0];
@@ -594,24 +595,41 @@ __global__ __launch_bounds__(256) void k_reduce_double(const double* __restrict_
     out[i] = (float)s;
 }
 
-// dX3[m, j] = sum_c dy1[m,c] * W1[c,j]      (one wave per row)
+// dX3[m, j] = sum_c dy1[m,c] * W1[c,j]: four lanes per row, 16 channels each (their W1 rows in registers), so a
+// wave reads 4 KiB of consecutive memory and a row costs two shuffle steps instead of six
 __global__ __launch_bounds__(256) void k_conv1_dgrad(const float* __restrict__ dy1, const float* __restrict__ W1,
                                                      float* __restrict__ dX3, int M) {
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    const float g = dy1[(size_t)m * 64 + lane];
-    float a0 = g * W1[3 * lane], a1 = g * W1[3 * lane + 1], a2 = g * W1[3 * lane + 2];
+    const int cg = threadIdx.x & 3;
+    float w[16][3];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        a0 += __shfl_xor(a0, off);
-        a1 += __shfl_xor(a1, off);
-        a2 += __shfl_xor(a2, off);
-    }
-    if (lane == 0) {
-        dX3[(size_t)m * 3 + 0] = a0;
-        dX3[(size_t)m * 3 + 1] = a1;
-        dX3[(size_t)m * 3 + 2] = a2;
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) w[i][j] = W1[(16 * cg + i) * 3 + j];
+    for (int m = blockIdx.x * 64 + (threadIdx.x >> 2); m < M; m += gridDim.x * 64) {
+        const float4* src = (const float4*)(dy1 + (size_t)m * 64 + 16 * cg);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 g = src[q];
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0 += gv[e] * w[4 * q + e][0];
+                a1 += gv[e] * w[4 * q + e][1];
+                a2 += gv[e] * w[4 * q + e][2];
+            }
+        }
+#pragma unroll
+        for (int off = 2; off >= 1; off >>= 1) {
+            a0 += __shfl_xor(a0, off);
+            a1 += __shfl_xor(a1, off);
+            a2 += __shfl_xor(a2, off);
+        }
+        if (cg == 0) {
+            dX3[(size_t)m * 3 + 0] = a0;
+            dX3[(size_t)m * 3 + 1] = a1;
+            dX3[(size_t)m * 3 + 2] = a2;
+        }
     }
 }
 
@@ -864,7 +882,11 @@ hipError_t t_conv1_bwd(const float* dy1, const float* X3, const float* W1, int M
     const int nblk = t_red_blocks(M);
     hipLaunchKernelGGL(k_conv1_wgrad, dim3(nblk), dim3(256), 0, s, dy1, X3, M, part);
     hipLaunchKernelGGL(k_reduce_double, grid1(192, FIN_COLS), dim3(256), 0, s, (const double*)part, nblk, 192, dW1);
-    if (dX3 != nullptr) hipLaunchKernelGGL(k_conv1_dgrad, dim3((M + 3) / 4), dim3(256), 0, s, dy1, W1, dX3, M);
+    if (dX3 != nullptr) {
+        int blocks = (M + 63) / 64;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_conv1_dgrad, dim3(blocks), dim3(256), 0, s, dy1, W1, dX3, M);
+    }
     return hipGetLastError();
 }
 hipError_t t_trans_grad(const float* x, const float* dX3, int B, int P, const float* dtrans_ext, float* dtrans,
