@@ -62,16 +62,26 @@ class CropResult:
         return [pts[off[g]:off[g + 1]] for g in range(self.n_grasps)]
 
 
+def _device_inputs(grasp_, pc):
+    """(scene float32 [S,3], grasps float64 [G,5,3]) on the scene's device (the current ROCm device for host data);
+    grasps may come as anything that reshapes to [G,5,3] (apps/kinect2grasp.py:385-389)."""
+    dev = pc.device if isinstance(pc, torch.Tensor) and pc.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    scene = torch.as_tensor(pc, dtype=torch.float32, device=dev).contiguous()
+    if scene.dim() != 2 or scene.shape[1] != 3:
+        raise ValueError("scene must be [S,3]")
+    if isinstance(grasp_, torch.Tensor) and grasp_.is_cuda:
+        grasps = grasp_.to(device=dev, dtype=torch.float64).reshape(-1, 5, 3).contiguous()
+    else:
+        host = np.asarray(grasp_.cpu() if isinstance(grasp_, torch.Tensor) else grasp_, dtype=np.float64)
+        grasps = torch.as_tensor(host.reshape(-1, 5, 3), device=dev).contiguous()
+    return scene, grasps, dev
+
+
 def collect_pc(grasp_, pc, limits, return_points=True) -> CropResult:
     """Crop the scene `pc` (float32 [S,3]) with every grasp of `grasp_` ([G,5,3] float64 or
     anything that reshapes to it, as in apps/kinect2grasp.py:385-389)."""
     lib = _lib.load()
-    dev = pc.device if isinstance(pc, torch.Tensor) and pc.is_cuda else torch.device("cuda", torch.cuda.current_device())
-    scene = torch.as_tensor(pc, dtype=torch.float32, device=dev).contiguous()
-    grasps = torch.as_tensor(np.asarray(grasp_.cpu() if isinstance(grasp_, torch.Tensor) else grasp_, dtype=np.float64)
-                             .reshape(-1, 5, 3), device=dev).contiguous()
-    if scene.dim() != 2 or scene.shape[1] != 3:
-        raise ValueError("scene must be [S,3]")
+    scene, grasps, dev = _device_inputs(grasp_, pc)
     S, G = scene.shape[0], grasps.shape[0]
     lim = (ctypes.c_double * 6)(*[float(v) for v in limits])
     nbytes = lib.pngpd_crop_workspace_bytes(S, G)
@@ -128,14 +138,7 @@ def crop_subsample(grasp_, pc, limits, num_points: int, repeat: int = 3, seed: i
     subsample(collect_pc(...), seed=seed).  overflow[0] != 0 means some grasp held more points than the kernel
     keeps on chip and its rows were not written: call collect_pc + subsample then (score_grasps does)."""
     lib = _lib.load()
-    dev = pc.device if isinstance(pc, torch.Tensor) and pc.is_cuda else torch.device("cuda", torch.cuda.current_device())
-    scene = torch.as_tensor(pc, dtype=torch.float32, device=dev).contiguous()
-    grasps = torch.as_tensor(np.asarray(grasp_.cpu() if isinstance(grasp_, torch.Tensor) else grasp_, dtype=np.float64)
-                             .reshape(-1, 5, 3), device=dev).contiguous() \
-        if not (isinstance(grasp_, torch.Tensor) and grasp_.is_cuda and grasp_.dtype == torch.float64) \
-        else grasp_.reshape(-1, 5, 3).contiguous()
-    if scene.dim() != 2 or scene.shape[1] != 3:
-        raise ValueError("scene must be [S,3]")
+    scene, grasps, dev = _device_inputs(grasp_, pc)
     S, G = scene.shape[0], grasps.shape[0]
     lim = (ctypes.c_double * 6)(*[float(v) for v in limits])
     nbytes = lib.pngpd_crop_workspace_bytes(S, G)
