@@ -133,9 +133,12 @@ constexpr int WS_WAVES = 8;
 constexpr int WS_THREADS = WS_WAVES * 64;
 constexpr int W16_TILE_BYTES = 4096;                       // [ks4][lane64][16 B]
 constexpr int W16_BATCH_TILES = 2 * WS_WAVES;
+// Wave priority while producing / consuming: the wave that feeds the matrix pipe goes first.  Measured with two
+// builds alternating on one box (tools/diag/ab_bench.sh): consume above produce +0.7..0.9 % over the reverse,
+// levels 1, 2, 3 alike.
 #ifndef PNGPD_PRIO_PRODUCE
-#define PNGPD_PRIO_PRODUCE 3
-#define PNGPD_PRIO_CONSUME 0
+#define PNGPD_PRIO_PRODUCE 0
+#define PNGPD_PRIO_CONSUME 3
 #endif
 #ifndef PNGPD_PRODUCER_WAVES
 #define PNGPD_PRODUCER_WAVES 8
