@@ -61,7 +61,6 @@ __global__ __launch_bounds__(256) void crop_mask_kernel(const float* __restrict_
         pz[k] = (double)p[2];
     }
     const int g_end = min(CROP_GB, G - gb * CROP_GB);
-#pragma unroll 2
     for (int j = 0; j < g_end; ++j) {
         const double* f = frames + (size_t)(gb * CROP_GB + j) * 12;   // wave-uniform: scalar loads
 #pragma unroll
