@@ -516,7 +516,7 @@ __global__ __launch_bounds__(1024) void k_conv3_sparse_dgrad(const float* __rest
     // a piece may continue in a neighbouring piece: they go to an LDS edge list that wave 0 combines in order.
     __shared__ float s_edge[32][C2];
     __shared__ int s_edge_row[32];
-    float* dhb = dh + (size_t)b * P * C2 + 2 * lane;
+    float* dhb = dh + (size_t)b * P * C2 + lane;      // lane owns columns lane and lane + 64: every add instruction covers 256 consecutive bytes
     const int begin = wave * 64, end = begin + 64;
     int cur = -1, runs = 0;
     float2 acc = make_float2(0.f, 0.f);
@@ -524,12 +524,12 @@ __global__ __launch_bounds__(1024) void k_conv3_sparse_dgrad(const float* __rest
         if (cur < 0) return;
         if (runs == 1 || last) {
             const int e = 2 * wave + (runs == 1 ? 0 : 1);
-            s_edge[e][2 * lane] = acc.x;
-            s_edge[e][2 * lane + 1] = acc.y;
+            s_edge[e][lane] = acc.x;
+            s_edge[e][64 + lane] = acc.y;
             if (lane == 0) s_edge_row[e] = cur;
         } else {
             unsafeAtomicAdd(dhb + (size_t)cur * C2, acc.x);
-            unsafeAtomicAdd(dhb + (size_t)cur * C2 + 1, acc.y);
+            unsafeAtomicAdd(dhb + (size_t)cur * C2 + 64, acc.y);
         }
     };
     if (lane == 0) s_edge_row[2 * wave + 1] = -1;     // stays empty when the piece is a single run
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(1024) void k_conv3_sparse_dgrad(const float* __rest
             const int ch = key & (C3 - 1);
             row[u] = key >> 10;
             cf[u] = s_coef[ch];
-            w[u] = *(const float2*)(W3 + (size_t)ch * C2 + 2 * lane);
+            w[u] = make_float2(W3[(size_t)ch * C2 + lane], W3[(size_t)ch * C2 + 64 + lane]);
         }
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u) {
@@ -569,17 +569,17 @@ __global__ __launch_bounds__(1024) void k_conv3_sparse_dgrad(const float* __rest
         if (r != cur) {
             if (cur >= 0) {
                 unsafeAtomicAdd(dhb + (size_t)cur * C2, acc.x);
-                unsafeAtomicAdd(dhb + (size_t)cur * C2 + 1, acc.y);
+                unsafeAtomicAdd(dhb + (size_t)cur * C2 + 64, acc.y);
             }
             cur = r;
             acc = make_float2(0.f, 0.f);
         }
-        acc.x += s_edge[e][2 * lane];
-        acc.y += s_edge[e][2 * lane + 1];
+        acc.x += s_edge[e][lane];
+        acc.y += s_edge[e][64 + lane];
     }
     if (cur >= 0) {
         unsafeAtomicAdd(dhb + (size_t)cur * C2, acc.x);
-        unsafeAtomicAdd(dhb + (size_t)cur * C2 + 1, acc.y);
+        unsafeAtomicAdd(dhb + (size_t)cur * C2 + 64, acc.y);
     }
 }
 
