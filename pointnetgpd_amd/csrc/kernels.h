@@ -153,7 +153,7 @@ hipError_t t_points_to_rows(const float* x, const float* trans, float* X3, int B
 int t_x3_blocks(int M);
 hipError_t t_conv1_bn_fwd(const float* X3, const float* W1, const float* b1, const float* gamma, const float* beta,
                           float momentum, double* part, float* mean, float* rstd, float* running_mean,
-                          float* running_var, float* y1, float* h1, int M, hipStream_t s);
+                          float* running_var, float* h1, int M, hipStream_t s);
 hipError_t t_fc_bn_fwd(const float* X, const float* W, const float* b, const float* gamma, const float* beta, int M,
                        int N, int K, float momentum, double* part, float* splitk_part, float* Z, float* A, float* mean,
                        float* rstd, float* running_mean, float* running_var, hipStream_t s);
@@ -163,7 +163,8 @@ hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, co
                         float* h, int M, int C, int relu, hipStream_t s);
 hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean, const float* rstd,
                     const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
-                    float* dbeta, float* dbias_zero, hipStream_t s);
+                    float* dbeta, float* dbias_zero, hipStream_t s,
+                    const float* conv1_x3 = nullptr, const float* conv1_w = nullptr, const float* conv1_b = nullptr);
 
 // conv3 + BatchNorm (batch statistics) + max over points without the [M,1024] activation (train_conv3.hip)
 struct Conv3Ws {

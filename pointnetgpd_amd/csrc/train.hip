@@ -112,19 +112,19 @@ __global__ __launch_bounds__(576) void k_conv1_stats(const double* __restrict__ 
     }
 }
 
-// y1[m, c] = W1[c,:] . X3[m,:] + b1[c] (64 channels) and h1 = relu((y1 - mean)*rstd*gamma + beta); 4 rows per 256-thread block
+// h1 = relu((y1 - mean)*rstd*gamma + beta) with y1[m, c] = W1[c,:] . X3[m,:] + b1[c] (64 channels), which is not
+// stored: the backward pass recomputes it from the points; 4 rows per 256-thread block
 __global__ __launch_bounds__(256) void k_conv1_bn_fwd(const float* __restrict__ X3, const float* __restrict__ W1,
                                                       const float* __restrict__ b1, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float* __restrict__ y1,
-                                                      float* __restrict__ h1, int M) {
+                                                      const float* __restrict__ beta, float* __restrict__ h1,
+                                                      int M) {
     const int c = threadIdx.x & 63;
     const float w0 = W1[3 * c], w1 = W1[3 * c + 1], w2 = W1[3 * c + 2], bb = b1[c];
     const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
     for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += gridDim.x * 4) {
         const float* xr = X3 + (size_t)m * 3;
         const float y = w0 * xr[0] + w1 * xr[1] + w2 * xr[2] + bb;
-        y1[(size_t)m * 64 + c] = y;
         h1[(size_t)m * 64 + c] = fmaxf((y - mu) * rs * ga + be, 0.f);
     }
 }
@@ -141,7 +141,11 @@ constexpr int RED_ROWS = 256;   // rows per block
 __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ A, const float* __restrict__ H,
                                                    const float* __restrict__ Y, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, int M, int C, int mode,
-                                                   int rows_per_block, double* __restrict__ part) {
+                                                   int rows_per_block, double* __restrict__ part,
+                                                   const float* __restrict__ X3, const float* __restrict__ W1,
+                                                   const float* __restrict__ b1) {
+    // X3 != nullptr (mode 1, C = 64): Y is conv1's output and is recomputed from the three coordinates of the row
+    // (y = W1 x + b1) instead of being read: 12 bytes per row instead of 256
     __shared__ double red[2][256 * 4];       // [s1|s2][row lane][column of the block]
     const int cq = C >> 2;
     const int QB = cq < 64 ? cq : 64, RL = 256 / QB;
@@ -163,10 +167,28 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ A, 
             }
         } else {
             const float4 mu = *(const float4*)(mean + col), rs = *(const float4*)(rstd + col);
+            float wq[4][3] = {}, bq[4] = {};
+            if (X3 != nullptr)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    wq[e][0] = W1[(col + e) * 3];
+                    wq[e][1] = W1[(col + e) * 3 + 1];
+                    wq[e][2] = W1[(col + e) * 3 + 2];
+                    bq[e] = b1[col + e];
+                }
 #pragma unroll 4
             for (int r = r0 + rl; r < r1; r += RL) {
                 float4 g = *(const float4*)(A + (size_t)r * C + col);
-                const float4 y = *(const float4*)(Y + (size_t)r * C + col);
+                float4 y;
+                if (X3 != nullptr) {
+                    const float x0 = X3[(size_t)r * 3], x1 = X3[(size_t)r * 3 + 1], x2 = X3[(size_t)r * 3 + 2];
+                    y.x = wq[0][0] * x0 + wq[0][1] * x1 + wq[0][2] * x2 + bq[0];
+                    y.y = wq[1][0] * x0 + wq[1][1] * x1 + wq[1][2] * x2 + bq[1];
+                    y.z = wq[2][0] * x0 + wq[2][1] * x1 + wq[2][2] * x2 + bq[2];
+                    y.w = wq[3][0] * x0 + wq[3][1] * x1 + wq[3][2] * x2 + bq[3];
+                } else {
+                    y = *(const float4*)(Y + (size_t)r * C + col);
+                }
                 if (H != nullptr) {
                     const float4 hv = *(const float4*)(H + (size_t)r * C + col);
                     if (!(hv.x > 0.f)) g.x = 0.f;
@@ -431,6 +453,51 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dense(float* __restrict__ dh, co
     o.z = ga.z * rv.z * (gv.z - a1.z - (yv.z - mv.z) * rv.z * a2.z);
     o.w = ga.w * rv.w * (gv.w - a1.w - (yv.w - mv.w) * rv.w * a2.w);
     ((float4*)dh)[i] = o;
+}
+
+// k_bn_bwd_dense for conv1's BatchNorm (C = 64) with y = W1 x + b1 recomputed from the row's coordinates.
+// block = 16 column quads x 16 row lanes over 256 rows: a thread keeps the weights of its four channels.
+__global__ __launch_bounds__(256) void k_conv1_bn_bwd_dense(float* __restrict__ dh, const float* __restrict__ h,
+                                                            const float* __restrict__ X3,
+                                                            const float* __restrict__ W1,
+                                                            const float* __restrict__ b1,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ m1,
+                                                            const float* __restrict__ m2, int M) {
+    const int col = (threadIdx.x & 15) * 4, rl = threadIdx.x >> 4;
+    float wq[4][3], bq[4], mu[4], rs[4], gr[4], a1[4], a2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        wq[e][0] = W1[(col + e) * 3];
+        wq[e][1] = W1[(col + e) * 3 + 1];
+        wq[e][2] = W1[(col + e) * 3 + 2];
+        bq[e] = b1[col + e];
+        mu[e] = mean[col + e];
+        rs[e] = rstd[col + e];
+        gr[e] = gamma[col + e] * rs[e];
+        a1[e] = m1[col + e];
+        a2[e] = m2[col + e];
+    }
+    const int r0 = blockIdx.x * 256;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        const int r = r0 + rl + 16 * j;
+        if (r >= M) break;
+        const float x0 = X3[(size_t)r * 3], x1 = X3[(size_t)r * 3 + 1], x2 = X3[(size_t)r * 3 + 2];
+        const float4 gv = *(const float4*)(dh + (size_t)r * 64 + col);
+        const float4 hv = *(const float4*)(h + (size_t)r * 64 + col);
+        const float g[4] = {hv.x > 0.f ? gv.x : 0.f, hv.y > 0.f ? gv.y : 0.f, hv.z > 0.f ? gv.z : 0.f,
+                            hv.w > 0.f ? gv.w : 0.f};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y = wq[e][0] * x0 + wq[e][1] * x1 + wq[e][2] * x2 + bq[e];
+            o[e] = gr[e] * (g[e] - a1[e] - (y - mu[e]) * rs[e] * a2[e]);
+        }
+        *(float4*)(dh + (size_t)r * 64 + col) = make_float4(o[0], o[1], o[2], o[3]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -765,12 +832,12 @@ hipError_t t_points_to_rows(const float* x, const float* trans, float* X3, int B
     hipLaunchKernelGGL(k_points_to_rows, grid1((size_t)B * P), dim3(256), 0, s, x, trans, X3, B, P);
     return hipGetLastError();
 }
-// conv1 + BatchNorm (batch statistics from the moments of the points) + ReLU: writes y1 (kept for the backward
-// pass), h1, mean, rstd and updates the running statistics.  part: t_x3_blocks(M) * 9 doubles.
+// conv1 + BatchNorm (batch statistics from the moments of the points) + ReLU: writes h1, mean, rstd and updates the
+// running statistics.  part: t_x3_blocks(M) * 9 doubles.
 int t_x3_blocks(int M) { return (M + X3M_ROWS - 1) / X3M_ROWS; }
 hipError_t t_conv1_bn_fwd(const float* X3, const float* W1, const float* b1, const float* gamma, const float* beta,
                           float momentum, double* part, float* mean, float* rstd, float* running_mean,
-                          float* running_var, float* y1, float* h1, int M, hipStream_t s) {
+                          float* running_var, float* h1, int M, hipStream_t s) {
     const int nblk = t_x3_blocks(M);
     hipLaunchKernelGGL(k_x3_moments, dim3(nblk), dim3(256), 0, s, X3, M, part);
     hipLaunchKernelGGL(k_conv1_stats, dim3(1), dim3(576), 0, s, (const double*)part, nblk, M, W1, b1, momentum, mean, rstd,
@@ -778,7 +845,7 @@ hipError_t t_conv1_bn_fwd(const float* X3, const float* W1, const float* b1, con
     int blocks = (M + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_conv1_bn_fwd, dim3(blocks), dim3(256), 0, s, X3, W1, b1, (const float*)mean, (const float*)rstd,
-                       gamma, beta, y1, h1, M);
+                       gamma, beta, h1, M);
     return hipGetLastError();
 }
 int t_red_blocks(int M) { return (M + RED_ROWS - 1) / RED_ROWS; }
@@ -795,7 +862,7 @@ hipError_t t_bn_stats(const float* A, int M, int C, float momentum, double* part
     const int nblk = t_colreduce_blocks(M);
     hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, A, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, 0,
-                       t_colreduce_rows(M), part);
+                       t_colreduce_rows(M), part, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     hipLaunchKernelGGL(k_stats_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, A, M, C, momentum, mean, rstd,
                        running_mean, running_var);
     return hipGetLastError();
@@ -831,10 +898,13 @@ hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, co
     return hipGetLastError();
 }
 // dh (in place) <- dy ; also dgamma, dbeta
+// conv1_x3 / conv1_w / conv1_b given (C = 64): y is conv1's output and is recomputed from the points instead of read
 hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean, const float* rstd,
                     const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
-                    float* dbeta, float* dbias_zero, hipStream_t s) {
-    if (M <= FEW_ROWS_MAX && C % 16 == 0 && h != nullptr) {
+                    float* dbeta, float* dbias_zero, hipStream_t s, const float* conv1_x3, const float* conv1_w,
+                    const float* conv1_b) {
+    if (conv1_x3 != nullptr && (C != 64 || !conv1_w || !conv1_b || !h)) return hipErrorInvalidValue;
+    if (M <= FEW_ROWS_MAX && C % 16 == 0 && h != nullptr && conv1_x3 == nullptr) {
         if (M <= 256)
             hipLaunchKernelGGL(k_few_rows_bn_bwd<16>, dim3(C / 16), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, M, C,
                                dgamma, dbeta, dbias_zero);
@@ -845,11 +915,15 @@ hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean
     }
     const int nblk = t_colreduce_blocks(M);
     hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, (const float*)dh, h, y, mean, rstd, M,
-                       C, 1, t_colreduce_rows(M), part);
+                       C, 1, t_colreduce_rows(M), part, conv1_x3, conv1_w, conv1_b);
     hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta,
                        dbias_zero);
-    hipLaunchKernelGGL(k_bn_bwd_dense, grid1((size_t)M * C / 4), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, m1, m2,
-                       (size_t)M * C / 4, C);
+    if (conv1_x3 != nullptr)
+        hipLaunchKernelGGL(k_conv1_bn_bwd_dense, dim3((M + 255) / 256), dim3(256), 0, s, dh, h, conv1_x3, conv1_w, conv1_b,
+                           mean, rstd, gamma, (const float*)m1, (const float*)m2, M);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_dense, grid1((size_t)M * C / 4), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, m1, m2,
+                           (size_t)M * C / 4, C);
     return hipGetLastError();
 }
 hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s,

@@ -25,7 +25,7 @@ struct Bump {
 };
 
 struct StackWs {
-    float *X3, *y1, *h1, *y2, *h2, *pooled, *dh2, *dh1, *dX3;
+    float *X3, *h1, *y2, *h2, *pooled, *dh2, *dh1, *dX3;      // conv1's pre-activation is recomputed, not stored
     int* arg;
     float *mean[3], *rstd[3];
     pngpd::Conv3Ws c3;
@@ -49,7 +49,6 @@ struct TrainWs {
         const size_t M = (size_t)B * P;
         for (StackWs* s : {&stn, &trunk}) {
             s->X3 = a.take<float>(M * 3);
-            s->y1 = a.take<float>(M * C1);
             s->h1 = a.take<float>(M * C1);
             s->y2 = a.take<float>(M * C2);
             s->h2 = a.take<float>(M * C2);
@@ -144,10 +143,10 @@ int fwd_stack(StackWs& S, float* const* p, int u1, const float* x, const float* 
               float momentum, double* part, double* gram_part, hipStream_t s) {
     const int M = B * P;
     HIP_TRY(pngpd::t_points_to_rows(x, trans, S.X3, B, P, s));
-    // conv1 + bn1 + relu: statistics from the moments of the points, one pass that writes y1 and h1
+    // conv1 + bn1 + relu: statistics from the moments of the points, one pass that writes h1
     HIP_TRY(pngpd::t_conv1_bn_fwd(S.X3, slot(p, u1, PNGPD_F_WEIGHT), slot(p, u1, PNGPD_F_BIAS),
                                   slot(p, u1, PNGPD_F_BN_WEIGHT), slot(p, u1, PNGPD_F_BN_BIAS), momentum, part, S.mean[0],
-                                  S.rstd[0], slot(p, u1, PNGPD_F_BN_MEAN), slot(p, u1, PNGPD_F_BN_VAR), S.y1, S.h1, M, s));
+                                  S.rstd[0], slot(p, u1, PNGPD_F_BN_MEAN), slot(p, u1, PNGPD_F_BN_VAR), S.h1, M, s));
     // conv2 with the column statistics of its output taken from the accumulators; relu(bn(conv2)) is applied by
     // the first pass of the conv3 block over these rows (t_conv3_fwd)
     HIP_TRY(pngpd::launch_tall_gemm(S.h1, slot(p, u1 + 1, PNGPD_F_WEIGHT), 0, slot(p, u1 + 1, PNGPD_F_BIAS), S.y2, M, C2,
@@ -217,9 +216,9 @@ int bwd_stack(StackWs& S, const float* const* p, float* const* g, int u1, const 
     HIP_TRY(pngpd::t_gemm_tn(S.dh2, S.h1, W.tn_part, slot(g, u1 + 1, PNGPD_F_WEIGHT), M, C2, C1, s));
     HIP_TRY(pngpd::launch_tall_gemm(S.dh2, cslot(p, u1 + 1, PNGPD_F_WEIGHT), 1, nullptr, S.dh1, M, C1, C2, 0, nullptr, s));
     // conv1 / bn1
-    HIP_TRY(pngpd::t_bn_bwd(S.dh1, S.h1, S.y1, S.mean[0], S.rstd[0], cslot(p, u1, PNGPD_F_BN_WEIGHT), M, C1, W.part,
+    HIP_TRY(pngpd::t_bn_bwd(S.dh1, S.h1, nullptr, S.mean[0], S.rstd[0], cslot(p, u1, PNGPD_F_BN_WEIGHT), M, C1, W.part,
                             W.m1, W.m2, slot(g, u1, PNGPD_F_BN_WEIGHT), slot(g, u1, PNGPD_F_BN_BIAS),
-                            slot(g, u1, PNGPD_F_BIAS), s));
+                            slot(g, u1, PNGPD_F_BIAS), s, S.X3, cslot(p, u1, PNGPD_F_WEIGHT), cslot(p, u1, PNGPD_F_BIAS)));
     HIP_TRY(pngpd::t_conv1_bwd(S.dh1, S.X3, cslot(p, u1, PNGPD_F_WEIGHT), M, W.part, slot(g, u1, PNGPD_F_WEIGHT),
                                need_dX3 ? S.dX3 : nullptr, s));
     return PNGPD_OK;
