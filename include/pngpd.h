@@ -114,6 +114,21 @@ int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, in
                         void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /*
+ * pngpd_forward_infer without a workspace argument and without any allocation.  It has no counterpart in the
+ * reference; it is for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  The per-batch intermediates (11.3 KB per candidate) live in a device
+ * array inside the library, PNGPD_NOALLOC_MAX_B * 11.3 KB = 2.9 MB, which every GPU the library runs on holds
+ * until the process ends; its address is looked up once per device in pngpd_model_create.  The call itself
+ * allocates and frees nothing.  Same arguments, kernels and results (bit for bit) as pngpd_forward_infer;
+ * B > PNGPD_NOALLOC_MAX_B returns PNGPD_ERR_SHAPE.  All calls on one GPU share the one array: two calls that
+ * overlap on a GPU (different streams or threads) race; calls on one stream are ordered and safe.
+ */
+#define PNGPD_NOALLOC_MAX_B 256
+int pngpd_forward_infer_noalloc(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
+                                int precision, float* logp_dev, float* trans_dev, float* feat_dev,
+                                void* stream);
+
+/*
  * softmax over the log-probabilities and first-index arg-max, i.e. the tail of
  * test_network() (main_test.py:80-83) for a whole batch.
  * probs_dev [B,k] float32, pred_dev [B] int64.

@@ -12,6 +12,7 @@ OK = 0
 FP32, BF16 = 0, 1
 LAYOUT_C3P, LAYOUT_P3 = 0, 1
 PART_STN, PART_TRUNK, PART_HEAD = 1, 2, 4
+NOALLOC_MAX_B = 256
 UNITS = ("stn_conv1", "stn_conv2", "stn_conv3", "stn_fc1", "stn_fc2", "stn_fc3",
          "feat_conv1", "feat_conv2", "feat_conv3", "fc1", "fc2", "fc3")
 FIELDS = ("weight", "bias", "bn_weight", "bn_bias", "bn_mean", "bn_var")
@@ -38,6 +39,8 @@ SIGNATURES = {
     "pngpd_forward_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "pngpd_forward_infer": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pngpd_forward_infer_noalloc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                            c_void_p, c_void_p]),
     "pngpd_forward_infer_timed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_size_t, c_void_p, c_void_p]),
     "pngpd_crop_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <new>
 #include <string>
 #include <vector>
@@ -190,6 +191,37 @@ pngpd::ConvStackArgs stack_args(const StackDev& d, int precision, const float* x
 
 }  // namespace
 
+// ---- workspace of pngpd_forward_infer_noalloc -------------------------------------------------------------
+// The per-batch intermediates of a forward (pooled maxima, the two hidden FC layers, the global feature, the
+// transform) for up to PNGPD_NOALLOC_MAX_B candidates live in a device array of the library's code object
+// instead of a caller workspace.  Every GPU the library runs on holds its own copy at its own address; in host
+// code the array's name is only a handle for hipGetSymbolAddress, never a device address.
+static_assert(PNGPD_NOALLOC_MAX_B >= 1, "PNGPD_NOALLOC_MAX_B");
+static constexpr size_t SCRATCH_FLOATS =
+    (size_t)PNGPD_NOALLOC_MAX_B * (1024 + 512 + 256 + 1024) + (((size_t)PNGPD_NOALLOC_MAX_B * 9 + 3) & ~(size_t)3);
+static __device__ __align__(256) float scratch[SCRATCH_FLOATS];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::atomic<float*> g_scratch_addr[MAX_DEVICES];
+
+// Device address of `scratch` on device `dev`, which must be the current device.  Looked up once per device.
+int scratch_on_current_device(int dev, float** out) {
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(PNGPD_ERR_INVALID, "device ordinal %d out of range", dev);
+    float* p = g_scratch_addr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        void* q = nullptr;
+        hipError_t e = hipGetSymbolAddress(&q, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !q)
+            return fail(PNGPD_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+        p = (float*)q;
+        g_scratch_addr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return PNGPD_OK;
+}
+}  // namespace
+
 extern "C" {
 
 const char* pngpd_last_error(void) { return g_last_error.c_str(); }
@@ -206,6 +238,9 @@ int pngpd_model_create(pngpd_model** out, int num_points, int k, int parts) {
         return fail(PNGPD_ERR_INVALID, "parts must be STN, STN|TRUNK or STN|TRUNK|HEAD, got %d", parts);
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    float* scratch_addr = nullptr;   // resolved here, at set-up, so that the first no-allocation forward only reads it
+    int rc = scratch_on_current_device(dev, &scratch_addr);
+    if (rc) return rc;
     pngpd_model* m = new (std::nothrow) pngpd_model();
     if (!m) return fail(PNGPD_ERR_INVALID, "out of host memory");
     m->device = dev;
@@ -310,6 +345,24 @@ int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, in
                         void* workspace_dev, size_t workspace_bytes, void* stream) {
     return forward_impl(m, x_dev, layout, B, P, precision, logp_dev, trans_dev, feat_dev, workspace_dev,
                         workspace_bytes, stream, nullptr);
+}
+
+int pngpd_forward_infer_noalloc(const pngpd_model* m, const float* x_dev, int layout, int B, int P, int precision,
+                                float* logp_dev, float* trans_dev, float* feat_dev, void* stream) {
+    if (!m) return fail(PNGPD_ERR_INVALID, "pngpd_forward_infer_noalloc: NULL model");
+    if (B > PNGPD_NOALLOC_MAX_B)
+        return fail(PNGPD_ERR_SHAPE, "pngpd_forward_infer_noalloc takes at most %d candidates per call, got %d "
+                    "(use pngpd_forward_infer with a caller workspace)", PNGPD_NOALLOC_MAX_B, B);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != m->device)
+        return fail(PNGPD_ERR_STATE, "model lives on device %d but device %d is current", m->device, dev);
+    float* ws = nullptr;
+    int rc = scratch_on_current_device(dev, &ws);
+    if (rc) return rc;
+    // every float of the workspace that a forward reads is written earlier in the same forward: nothing to clear
+    return forward_impl(m, x_dev, layout, B, P, precision, logp_dev, trans_dev, feat_dev, ws,
+                        SCRATCH_FLOATS * sizeof(float), stream, nullptr);
 }
 
 int pngpd_forward_infer_timed(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
