@@ -239,12 +239,15 @@ int pngpd_vote(const int64_t* pred_dev, const float* probs_dev, const uint8_t* v
  * points_dev [S,3] float32 -> the unique float32 centres of the occupied voxels of an n x n x n
  * grid over the point cloud's bounding box made cubic, in np.unique(axis=0) order (lexicographic),
  * written to out_dev [capacity,3]; *count_dev = number of unique centres (rows beyond `capacity`
- * are counted but not written).  Bin edges are float64 (np.linspace on float32 scalars under the
- * numpy 1.x promotion rules the reference was written for), centres float32.
+ * are counted but not written).  Centres are float32.  `edges` selects the type np.linspace forms the bin edges
+ * in, which is numpy's choice and not the reference's (the reference does not pin numpy): PNGPD_EDGES_F64 is what
+ * numpy 1.x does with two float32 scalars (the releases the reference was written for), PNGPD_EDGES_F32 what
+ * numpy >= 2 does; a point within an ulp of an edge, and the last bit of a centre, can differ between the two.
  * n in [1, 1600].  Workspace: pngpd_voxel_workspace_bytes(n) bytes (n^3 / 8 + small).
  * ------------------------------------------------------------------------------------------ */
+enum { PNGPD_EDGES_F64 = 0, PNGPD_EDGES_F32 = 1 };
 size_t pngpd_voxel_workspace_bytes(int n);
-int pngpd_voxel_unique(const float* points_dev, int S, int n, void* workspace_dev, size_t workspace_bytes,
+int pngpd_voxel_unique(const float* points_dev, int S, int n, int edges, void* workspace_dev, size_t workspace_bytes,
                        float* out_dev, int64_t capacity, int32_t* count_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -8,13 +8,14 @@ Restates (float64 numpy, like the reference):
   * subsample / pad         apps/kinect2grasp.py:746-774  (>= P: without replacement, else with)
   * repeat / vote           apps/kinect2grasp.py:764, 799-817
 
-Pinning.  apps/kinect2grasp.py cannot be imported (rospy, dexnet, pcl at import time) and the
-reference has no tests or fixtures for it, so this restatement is checked by reading only.
-`crop_numpy` keeps the reference's numpy calls (np.linalg.norm, np.dot of a 3x3 by 3xS matrix);
-`crop_pinned` spells out the operation order that those calls execute on the build container's
-numpy/OpenBLAS (a k-ordered fused-multiply-add chain) with no library call left, and
-tests/golden/crop_*.npz were produced by `crop_numpy`.  tests/test_crop_oracle.py shows the two
-agree bit for bit; oracle/crop_oracle.c is the same pinned order in C (used for large inputs).
+Pinning.  apps/kinect2grasp.py cannot be imported (rospy, dexnet, pcl at import time), but
+check_collision_square itself needs only numpy: tests/golden/make_crop_golden.py (build container only) takes
+that one function definition out of the reference file's syntax tree, runs it in collect_pc's order and stores
+its outputs as tests/golden/crop_*.npz.  tests/test_crop_oracle.py checks every form below against those files
+bit for bit: `crop_numpy` keeps the reference's numpy calls (np.linalg.norm, np.dot of a 3x3 by 3xS matrix);
+`crop_pinned` spells out the operation order that those calls execute on the build container's numpy/OpenBLAS
+(a k-ordered fused-multiply-add chain) with no library call left; oracle/crop_oracle.c is the same pinned
+order in C (used for large inputs).  Subsample and vote restate scalar logic and have no reference-run fixture.
 
 The gripper corner table comes from dex-net's get_hand_points (an un-vendored dependency,
 github.com/Hymwgk/dex-net, no pinned revision); `hand_points` restates its published construction

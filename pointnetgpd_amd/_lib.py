@@ -13,6 +13,7 @@ FP32, BF16 = 0, 1
 LAYOUT_C3P, LAYOUT_P3 = 0, 1
 PART_STN, PART_TRUNK, PART_HEAD = 1, 2, 4
 NOALLOC_MAX_B = 256
+EDGES_F64, EDGES_F32 = 0, 1
 UNITS = ("stn_conv1", "stn_conv2", "stn_conv3", "stn_fc1", "stn_fc2", "stn_fc3",
          "feat_conv1", "feat_conv2", "feat_conv3", "fc1", "fc2", "fc3")
 FIELDS = ("weight", "bias", "bn_weight", "bn_bias", "bn_mean", "bn_var")
@@ -59,7 +60,7 @@ SIGNATURES = {
                                           c_void_p]),
     "pngpd_vote": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pngpd_voxel_workspace_bytes": (c_size_t, [c_int]),
-    "pngpd_voxel_unique": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_void_p]),
+    "pngpd_voxel_unique": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_void_p]),
     "pngpd_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "pngpd_train_forward": (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p), c_int, c_float, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

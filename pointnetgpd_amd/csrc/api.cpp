@@ -226,7 +226,7 @@ extern "C" {
 
 const char* pngpd_last_error(void) { return g_last_error.c_str(); }
 
-int pngpd_abi_version(void) { return 1; }
+int pngpd_abi_version(void) { return 2; }
 
 int pngpd_model_create(pngpd_model** out, int num_points, int k, int parts) {
     if (!out) return fail(PNGPD_ERR_INVALID, "pngpd_model_create: out is NULL");
@@ -533,17 +533,19 @@ size_t pngpd_voxel_workspace_bytes(int n) {
     return pngpd::voxel_workspace_bytes(n);
 }
 
-int pngpd_voxel_unique(const float* points_dev, int S, int n, void* workspace_dev, size_t workspace_bytes,
+int pngpd_voxel_unique(const float* points_dev, int S, int n, int edges, void* workspace_dev, size_t workspace_bytes,
                        float* out_dev, int64_t capacity, int32_t* count_dev, void* stream) {
     if (!points_dev || !workspace_dev || !out_dev || !count_dev)
         return fail(PNGPD_ERR_INVALID, "pngpd_voxel_unique: NULL argument");
     if (S < 1 || n < 1 || n > pngpd::VOXEL_MAX_N || capacity < 0)
         return fail(PNGPD_ERR_SHAPE, "pngpd_voxel_unique: S=%d n=%d (1..%d) capacity=%lld", S, n, pngpd::VOXEL_MAX_N,
                     (long long)capacity);
+    if (edges != PNGPD_EDGES_F64 && edges != PNGPD_EDGES_F32)
+        return fail(PNGPD_ERR_INVALID, "pngpd_voxel_unique: unknown edge type %d", edges);
     if (workspace_bytes < pngpd::voxel_workspace_bytes(n))
         return fail(PNGPD_ERR_WORKSPACE, "pngpd_voxel_unique: workspace %zu < %zu bytes", workspace_bytes,
                     pngpd::voxel_workspace_bytes(n));
-    HIP_TRY(pngpd::launch_voxel_unique(points_dev, S, n, workspace_dev, out_dev, (long long)capacity, count_dev,
+    HIP_TRY(pngpd::launch_voxel_unique(points_dev, S, n, edges == PNGPD_EDGES_F32, workspace_dev, out_dev, (long long)capacity, count_dev,
                                        (hipStream_t)stream));
     return PNGPD_OK;
 }

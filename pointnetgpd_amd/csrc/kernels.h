@@ -116,8 +116,8 @@ hipError_t launch_vote(const long long* pred, const float* probs, const unsigned
 // ---- voxel down-sampling (voxel.hip) ------------------------------------------------------------
 constexpr int VOXEL_MAX_N = 1600;            // n^3 voxel keys must fit 32 bits
 size_t voxel_workspace_bytes(int n);
-hipError_t launch_voxel_unique(const float* pts, int S, int n, void* ws, float* out, long long capacity, int* count,
-                               hipStream_t s);
+hipError_t launch_voxel_unique(const float* pts, int S, int n, int f32_edges, void* ws, float* out, long long capacity,
+                               int* count, hipStream_t s);
 
 // ---- tall-matrix products (tall_gemm.hip) ------------------------------------------------------
 constexpr int TALL_GEMM_MAX_BLOCKS = 512;    // persistent workgroups: two per CU on a 256-CU part

@@ -7,12 +7,15 @@
 // keeps np.unique(rows): the unique centre triples in lexicographic order.
 //
 // Here: a float32 min/max reduction, one small setup block that redoes the reference's scalar
-// arithmetic operation by operation (float32 box, float64 edges = i*step + start with two
-// roundings, float32 centres), then one pass over the points that sets a bit per occupied voxel,
+// arithmetic operation by operation (float32 box, edges = i*step + start with two roundings,
+// float32 centres), then one pass over the points that sets a bit per occupied voxel,
 // and a popcount / scan / expand pass over the bitmap.  Ascending bit order is the lexicographic
 // order of the centres, so nothing is sorted.  Two voxels whose float32 centres coincide on an
 // axis are the same row to np.unique; each axis index is therefore first mapped to the lowest
 // index with the same float32 centre.
+// The type of the edges is numpy's choice, not the reference's: np.linspace on two float32 scalars works in
+// float64 under numpy 1.x (value-based promotion with its Python-float factor) and in float32 under numpy >= 2.
+// Both are implemented (f32_edges); they differ in the step and in the two roundings of every edge.
 // HBM-bound: S*12 bytes of points, n^3/8 bytes of bitmap written once and read twice.
 #include <hip/hip_runtime.h>
 
@@ -31,7 +34,7 @@ constexpr int VX_WORDS_PER_BLOCK = 1024;     // bitmap words per block of the co
 struct VoxelParams {
     double start[3], stop[3], step[3];
     int n;
-    int pad;
+    int f32_edges;   // 1: edges formed in float32 (numpy >= 2); start / stop / step then hold float32 values
 };
 
 struct VoxelWs {
@@ -101,12 +104,16 @@ __global__ __launch_bounds__(VX_THREADS) void k_vox_minmax(const float* pts, int
 __device__ __forceinline__ double vox_edge(const VoxelParams& p, int a, int i) {
     if (i >= p.n) return p.stop[a];
     if (p.step[a] == 0.0) return p.start[a];
+    if (p.f32_edges) {
+        const float t = (float)i * (float)p.step[a];
+        return (double)(t + (float)p.start[a]);
+    }
     const double t = (double)i * p.step[a];
     return t + p.start[a];
 }
 
-__global__ __launch_bounds__(VX_THREADS) void k_vox_setup(const float* partial, int nparts, int n, VoxelParams* prm,
-                                                          float* mid, int* canon) {
+__global__ __launch_bounds__(VX_THREADS) void k_vox_setup(const float* partial, int nparts, int n, int f32_edges,
+                                                          VoxelParams* prm, float* mid, int* canon) {
     __shared__ float s_mm[6];
     __shared__ float s_red[VX_THREADS / 64][6];
     __shared__ VoxelParams s_p;
@@ -151,14 +158,20 @@ __global__ __launch_bounds__(VX_THREADS) void k_vox_setup(const float* partial, 
             const float margin = m - d[a];
             const float half = margin / 2.0f;
             const float lo = s_mm[a] - half, hi = s_mm[3 + a] + half;
-            // float64 from here on (np.linspace on two float32 scalars and a Python float)
             s_p.start[a] = (double)lo;
             s_p.stop[a] = (double)hi;
-            const double delta = (double)hi - (double)lo;
-            s_p.step[a] = delta / (double)n;
+            if (f32_edges) {
+                // numpy >= 2: np.linspace on two float32 scalars stays in float32 (delta, step and every edge)
+                const float delta = hi - lo;
+                s_p.step[a] = (double)(delta / (float)n);
+            } else {
+                // numpy 1.x: float64 from here on (two float32 scalars and a Python float)
+                const double delta = (double)hi - (double)lo;
+                s_p.step[a] = delta / (double)n;
+            }
         }
         s_p.n = n;
-        s_p.pad = 0;
+        s_p.f32_edges = f32_edges;
         *prm = s_p;
     }
     __syncthreads();
@@ -300,8 +313,8 @@ size_t voxel_workspace_bytes(int n) {
            align256((vx_blocks(n) + 1) * 4) + align256(vx_words(n) * 4);
 }
 
-hipError_t launch_voxel_unique(const float* pts, int S, int n, void* ws, float* out, long long capacity, int* count,
-                               hipStream_t s) {
+hipError_t launch_voxel_unique(const float* pts, int S, int n, int f32_edges, void* ws, float* out, long long capacity,
+                               int* count, hipStream_t s) {
     const VoxelWs w = carve(ws, n);
     const size_t words = vx_words(n);
     const int nb = (int)vx_blocks(n);
@@ -310,7 +323,8 @@ hipError_t launch_voxel_unique(const float* pts, int S, int n, void* ws, float* 
     int red_blocks = (S + VX_THREADS - 1) / VX_THREADS;
     red_blocks = red_blocks < VX_RED_BLOCKS ? red_blocks : VX_RED_BLOCKS;
     hipLaunchKernelGGL(k_vox_minmax, dim3(red_blocks), dim3(VX_THREADS), 0, s, pts, S, w.partial);
-    hipLaunchKernelGGL(k_vox_setup, dim3(1), dim3(VX_THREADS), 0, s, w.partial, red_blocks, n, w.prm, w.mid, w.canon);
+    hipLaunchKernelGGL(k_vox_setup, dim3(1), dim3(VX_THREADS), 0, s, w.partial, red_blocks, n, f32_edges, w.prm, w.mid,
+                       w.canon);
     int mark_blocks = (S + VX_THREADS - 1) / VX_THREADS;
     mark_blocks = mark_blocks < 4096 ? mark_blocks : 4096;
     hipLaunchKernelGGL(k_vox_mark, dim3(mark_blocks), dim3(VX_THREADS), 0, s, pts, S, w.prm, w.canon, w.bitmap);

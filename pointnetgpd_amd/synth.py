@@ -143,6 +143,15 @@ def scene_points(seed: int, S: int, cube: float = 0.5) -> np.ndarray:
     return uniform(seed, "scene", (S, 3), 0.0, cube)
 
 
+def elongated_scene_points(seed: int, S: int, cube: float = 0.5) -> np.ndarray:
+    """scene_points squeezed to a flat slab away from the origin: a bounding box far from cubic, which the
+    voxel grid of the reference grows to a cube around itself (apps/voxelgrid.py:119-123)."""
+    pts = scene_points(seed, S, cube).copy()
+    pts[:, 1] *= np.float32(0.37)
+    pts[:, 2] = pts[:, 2] * np.float32(0.11) + np.float32(0.4)
+    return pts
+
+
 def random_grasps(seed: int, G: int, cube: float = 0.5, margin: float = 0.06) -> np.ndarray:
     """Grasp array float64 [G,5,3] in the layout collect_pc reads (apps/kinect2grasp.py:389-396):
     row 4 = bottom centre, rows 1,2,3 = approach, binormal, minor axis.  Axes form a random

@@ -43,6 +43,18 @@ def test_golden_random_case():
     np.testing.assert_array_equal(res.points_g.cpu().numpy()[:n_head], d["pts_head"])
 
 
+def test_golden_near_plane_case():
+    """Outputs of the reference's own check_collision_square on oblique grasps (axes not of unit length) with points
+    a few float32 ulps either side of every plane: index sets and gripper-frame float64 points, bit for bit."""
+    import hashlib
+    d = np.load(os.path.join(GOLDEN, "crop_near_planes.npz"))
+    res = hc.collect_pc(d["grasps"], torch.from_numpy(d["scene"]).cuda(), d["limits"])
+    np.testing.assert_array_equal(res.counts.cpu().numpy(), d["counts"])
+    np.testing.assert_array_equal(res.indices.cpu().numpy(), d["idx"])
+    for p, h in zip(res.point_lists(), d["pts_sha256"]):
+        assert hashlib.sha256(np.ascontiguousarray(p).tobytes()).hexdigest() == str(h)
+
+
 def test_golden_points_on_planes_are_excluded():
     d = np.load(os.path.join(GOLDEN, "crop_planes.npz"))
     res = hc.collect_pc(d["grasps"], torch.from_numpy(d["scene"]).cuda(), d["limits"])

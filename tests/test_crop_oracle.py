@@ -1,5 +1,6 @@
-"""CPU: the crop oracle's three forms (reference numpy calls / pinned fma order / plain C) agree
-bit for bit, match the committed golden vectors, and honour the strict inequalities."""
+"""CPU: the crop oracle's three forms (reference numpy calls / pinned fma order / plain C) agree bit for bit with
+the committed golden vectors - outputs of the reference's own check_collision_square (apps/kinect2grasp.py:299-374),
+taken out of the reference file and run by tests/golden/make_crop_golden.py - and honour the strict inequalities."""
 import hashlib
 import os
 
@@ -59,6 +60,23 @@ def test_points_on_the_planes_are_excluded():
         on, up, down = 1 + 3 * plane, 2 + 3 * plane, 3 + 3 * plane
         assert on not in idx0
         assert (up in idx0) != (down in idx0)
+
+
+def test_near_plane_golden_of_the_reference_function():
+    """Oblique grasps with axes of random length and points within a few float32 ulps of each plane."""
+    d = np.load(os.path.join(GOLDEN, "crop_near_planes.npz"))
+    assert 0 < d["counts"].min() and d["counts"].sum() < d["scene"].shape[0] * len(d["grasps"])
+    for fn in (co.crop_numpy, co.crop_c):
+        idx, pts = fn(d["grasps"], d["scene"], d["limits"])
+        np.testing.assert_array_equal([len(i) for i in idx], d["counts"])
+        np.testing.assert_array_equal(np.concatenate(idx), d["idx"])
+        for p, h in zip(pts, d["pts_sha256"]):
+            assert hashlib.sha256(np.ascontiguousarray(p).tobytes()).hexdigest() == str(h)
+    centre, a, b, m = co.split_grasps(d["grasps"])
+    start = np.concatenate([[0], np.cumsum(d["counts"])])
+    for g in (0, 7, 23):
+        i_pin, _ = co.crop_one_pinned(centre[g], a[g], b[g], m[g], d["scene"], d["limits"])
+        np.testing.assert_array_equal(i_pin, d["idx"][start[g]:start[g + 1]])
 
 
 def test_empty_crop_and_grasp_reshape():

@@ -1,6 +1,9 @@
 """GPU parity of pngpd_voxel_unique (through the C ABI) against the CPU restatement of
 get_voxel_fun (apps/kinect2grasp.py:145-150): the unique float32 voxel centres, bit-exact and in
-the same order.  The restatement itself is unpinned (the reference module needs numba)."""
+the same order, for both edge types; the float32-edge form also against outputs of the reference's own
+definitions (tests/golden/voxel_reference.npz, written by tests/golden/make_voxel_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -12,11 +15,24 @@ pytestmark = pytest.mark.gpu
 
 
 def _check(pts, n):
-    got = voxel.get_voxel_fun(torch.from_numpy(pts).cuda(), n).cpu().numpy()
-    want = vo.get_voxel_fun(pts, n)
-    assert got.shape == want.shape, (got.shape, want.shape)
-    np.testing.assert_array_equal(got, want)
+    for edges in ("float64", "float32"):
+        got = voxel.get_voxel_fun(torch.from_numpy(pts).cuda(), n, edges=edges).cpu().numpy()
+        want = vo.get_voxel_fun(pts, n, edges=edges)
+        assert got.shape == want.shape, (edges, got.shape, want.shape)
+        np.testing.assert_array_equal(got, want, err_msg=edges)
     return len(want)
+
+
+def test_reference_run_golden():
+    """Outputs of the reference's own cartesian / VoxelGrid / get_voxel_fun (numpy 2: float32 edges)."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voxel_reference.npz"))
+    for i, (seed, S, cube, n) in enumerate(d["cases"]):
+        make = synth.scene_points if i % 2 == 0 else synth.elongated_scene_points
+        pts = make(int(seed), int(S), float(cube))
+        got = voxel.get_voxel_fun(torch.from_numpy(pts).cuda(), int(n), edges="float32").cpu().numpy()
+        want = d[f"out_{i}"]
+        assert got.shape == want.shape, (i, got.shape, want.shape)
+        np.testing.assert_array_equal(got, want)
 
 
 @pytest.mark.parametrize("n", [1, 2, 7, 64, 500])

@@ -60,3 +60,32 @@ def test_restatement_regression_vectors():
     pts = synth.scene_points(int(d["seed"]), int(d["S"]), float(d["cube"]))
     for n in d["n"]:
         np.testing.assert_array_equal(vo.get_voxel_fun(pts, int(n)), d[f"out_n{int(n)}"])
+
+
+def _reference_cases():
+    import os
+    from pointnetgpd_amd import synth
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voxel_reference.npz"))
+    for i, (seed, S, cube, n) in enumerate(d["cases"]):
+        make = synth.scene_points if i % 2 == 0 else synth.elongated_scene_points
+        yield make(int(seed), int(S), float(cube)), int(n), d[f"out_{i}"]
+
+
+def test_float32_edge_form_equals_the_reference_run():
+    """tests/golden/voxel_reference.npz holds outputs of the reference's own cartesian / VoxelGrid / get_voxel_fun
+    (run under numpy 2, where the bin edges stay float32)."""
+    for pts, n, want in _reference_cases():
+        got = vo.get_voxel_fun(pts, n, edges="float32")
+        assert got.shape == want.shape
+        np.testing.assert_array_equal(got, want)
+
+
+def test_float64_edge_form_differs_from_it_only_in_the_last_bit():
+    """The numpy 1.x form (float64 edges) sees the same voxels up to points within an ulp of an edge, and centres
+    that agree to one float32 ulp."""
+    for pts, n, want in _reference_cases():
+        got = vo.get_voxel_fun(pts, n, edges="float64")
+        assert abs(len(got) - len(want)) <= max(2, len(want) // 200)
+        if got.shape == want.shape:
+            scale = np.abs(want).max()
+            assert np.abs(got - want).max() <= 2 * np.spacing(np.float32(scale))
