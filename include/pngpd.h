@@ -171,6 +171,18 @@ int pngpd_crop_count_frames(const float* scene_dev, int S, const double* frames_
                             const double* limits, void* workspace_dev, size_t workspace_bytes,
                             int32_t* cnt_dev, int64_t* offsets_dev, void* stream);
 
+/*
+ * The frames of the training-data crop, built on the device from the dataset's grasp records: the frame
+ * construction at the head of collect_pc_ (model/dataset.py:776-835).  records_dev float64 [G, record_stride]
+ * with fields 0-2 contact centre, 3-5 closing axis, 6 width, 7 angle (record_stride >= 8; the .npy records of the
+ * dataset carry two score fields behind them); transform: 16 host doubles, the view's 4x4 matrix row-major (:825-833);
+ * hand_depth = ags.gripper.hand_depth (:815).  frames_dev float64 [G,12] as pngpd_crop_count_frames takes them.
+ * sin / cos of the angle are the device library's: frames agree with a host float64 evaluation to a few units in
+ * the last place, not bit for bit.
+ */
+int pngpd_dataset_frames(const double* records_dev, int G, int record_stride, const double* transform,
+                         double hand_depth, double* frames_dev, void* stream);
+
 /* idx_dev int32 [idx_capacity]: for grasp g the ascending scene indices sit at
  * offsets[g] .. offsets[g+1]-1 (in_ind_, :413); entries at or beyond idx_capacity are dropped.
  * pts_g_dev (optional) float64 [idx_capacity,3]: the same points in the gripper frame

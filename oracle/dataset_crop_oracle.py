@@ -10,8 +10,8 @@ fixture for it.  ags.gripper.hand_depth and the corner table of ags.get_hand_poi
 import numpy as np
 
 
-def collect_pc_(grasp, pc, transform, hand_depth, hand_points, min_point_limit=50):
-    """Returns (in_ind, pc_c2g[in_ind]) or (in_ind, None) when fewer than min_point_limit points (:918)."""
+def frame_of_record(grasp, transform, hand_depth):
+    """(bottom_ [3], matrix [3,3]) of :776-835 for one grasp record, float64."""
     center = grasp[0:3]
     axis = grasp[3:6]
     angle = grasp[7]
@@ -37,6 +37,22 @@ def collect_pc_(grasp, pc, transform, hand_depth, hand_points, min_point_limit=5
     approach_ = (np.dot(transform, np.array([approach[0], approach[1], approach[2], 0])))[:3].reshape(3, 1)
     minor_normal_ = (np.dot(transform, np.array([minor_normal[0], minor_normal[1], minor_normal[2], 0])))[:3].reshape(3, 1)
     matrix = np.hstack([approach_, binormal_, minor_normal_]).T
+    return bottom_, matrix
+
+
+def frames_of_records(grasps, transform, hand_depth):
+    """[G,12] float64: bottom_ followed by the rows of `matrix`, the layout pngpd_crop_count_frames takes."""
+    out = np.empty((len(grasps), 12), dtype=np.float64)
+    for g, rec in enumerate(np.asarray(grasps, dtype=np.float64)):
+        b, m = frame_of_record(rec, np.asarray(transform, dtype=np.float64), hand_depth)
+        out[g, :3] = b
+        out[g, 3:] = m.reshape(9)
+    return out
+
+
+def collect_pc_(grasp, pc, transform, hand_depth, hand_points, min_point_limit=50):
+    """Returns (in_ind, pc_c2g[in_ind]) or (in_ind, None) when fewer than min_point_limit points (:918)."""
+    bottom_, matrix = frame_of_record(grasp, transform, hand_depth)
     pc_c2g = (np.dot(matrix, (pc - bottom_).T)).T                       # :843
     s1, s2, s4, s8 = hand_points[1], hand_points[2], hand_points[4], hand_points[8]
     a1 = s1[1] < pc_c2g[:, 1]

@@ -55,6 +55,7 @@ SIGNATURES = {
                                      c_int, c_int, c_uint64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pngpd_crop_count_frames": (c_int, [c_void_p, c_int, c_void_p, c_int, POINTER(c_double), c_void_p, c_size_t,
                                         c_void_p, c_void_p, c_void_p]),
+    "pngpd_dataset_frames": (c_int, [c_void_p, c_int, c_int, POINTER(c_double), c_double, c_void_p, c_void_p]),
     "pngpd_crop_gather_dataset": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                           c_int, c_int, c_void_p, c_uint64, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p]),

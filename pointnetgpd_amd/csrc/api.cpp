@@ -454,6 +454,17 @@ int pngpd_crop_count_frames(const float* scene_dev, int S, const double* frames_
     return PNGPD_OK;
 }
 
+int pngpd_dataset_frames(const double* records_dev, int G, int record_stride, const double* transform,
+                         double hand_depth, double* frames_dev, void* stream) {
+    if (!records_dev || !transform || !frames_dev) return fail(PNGPD_ERR_INVALID, "pngpd_dataset_frames: NULL argument");
+    if (G < 1 || record_stride < 8)
+        return fail(PNGPD_ERR_SHAPE, "pngpd_dataset_frames: G=%d record_stride=%d (a record has at least 8 fields)", G,
+                    record_stride);
+    HIP_TRY(pngpd::launch_dataset_frames(records_dev, record_stride, G, transform, hand_depth, frames_dev,
+                                         (hipStream_t)stream));
+    return PNGPD_OK;
+}
+
 int pngpd_crop_emit(const float* scene_dev, int S, int G, const double* limits, const void* workspace_dev,
                     size_t workspace_bytes, const int32_t* cnt_dev, const int64_t* offsets_dev, int32_t* idx_dev,
                     int64_t idx_capacity, double* pts_g_dev, void* stream) {

@@ -42,6 +42,81 @@ __global__ void crop_frames_kernel(const double* __restrict__ grasps, double* __
     }
 }
 
+// Gripper frame of a training-data grasp record in the frame of one view (model/dataset.py:776-835), written
+// from the geometry.  A record holds the contact centre c, the closing axis a, the opening width and the angle t
+// by which the approach direction is turned about the closing axis; T is the view's 4x4 transform, hd the hand
+// depth.
+//     y = a / |a|                                  closing axis (binormal)
+//     x = (y1, -y0, 0) / |.|   ((1,0,0) when that vanishes)     a horizontal direction orthogonal to y
+//     z = x cross (y / |y|)
+//     approach = (cos t * x + sin t * z) / |.|     first column of [x y z] * Ry(t)
+//     minor    = y cross approach
+//     bottom   = c - hd * approach                 the frame's origin: the bottom centre of the open hand
+// and every one of them goes through T (points with w = 1, directions with w = 0; the transformed axes are NOT
+// re-normalised).  Output row: bottom, approach, binormal, minor = the [G,12] frames pngpd_crop_count_frames takes.
+// Products and sums are separate roundings (contraction is off in this file) except where an fma is written: the
+// norms and the two-term combination, which is where numpy's BLAS calls fuse; a 4-term row of T * v is summed as
+// (p0 + p2) + (p1 + p3).  sin / cos come from the device maths library: against a host evaluation the frames agree
+// to a few units in the last place, not bit for bit.
+struct Transform4 { double m[16]; };
+
+__device__ __forceinline__ double norm3(double x, double y, double z) { return sqrt(fma(z, z, fma(y, y, x * x))); }
+
+__device__ __forceinline__ void apply_t(const Transform4& T, double v0, double v1, double v2, double w, double* out) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double p0 = T.m[4 * r + 0] * v0, p1 = T.m[4 * r + 1] * v1, p2 = T.m[4 * r + 2] * v2, p3 = T.m[4 * r + 3] * w;
+        out[r] = (p0 + p2) + (p1 + p3);
+    }
+}
+
+__global__ void dataset_frames_kernel(const double* __restrict__ records, int stride, int G, Transform4 T,
+                                      double hand_depth, double* __restrict__ frames) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const double* rec = records + (size_t)g * stride;
+    const double cx = rec[0], cy = rec[1], cz = rec[2], angle = rec[7];
+    double n = norm3(rec[3], rec[4], rec[5]);
+    const double y0 = rec[3] / n, y1 = rec[4] / n, y2 = rec[5] / n;
+    double x0 = y1, x1 = -y0, x2 = 0.0;
+    n = norm3(x0, x1, x2);
+    if (n == 0.0) {
+        x0 = 1.0;
+        x1 = 0.0;
+        n = 1.0;
+    }
+    x0 /= n;
+    x1 /= n;
+    x2 /= n;
+    n = norm3(y0, y1, y2);                               // the reference normalises the axis a second time here
+    const double u0 = y0 / n, u1 = y1 / n, u2 = y2 / n;
+    const double z0 = x1 * u2 - x2 * u1, z1 = x2 * u0 - x0 * u2, z2 = x0 * u1 - x1 * u0;
+    const double c = cos(angle), s = sin(angle);
+    // column 0 of [x u z] * Ry: the middle term u * 0 adds an exact zero
+    double a0 = fma(z0, s, fma(u0, 0.0, x0 * c)), a1 = fma(z1, s, fma(u1, 0.0, x1 * c)), a2 = fma(z2, s, fma(u2, 0.0, x2 * c));
+    n = norm3(a0, a1, a2);
+    a0 /= n;
+    a1 /= n;
+    a2 /= n;
+    const double m0 = y1 * a2 - y2 * a1, m1 = y2 * a0 - y0 * a2, m2 = y0 * a1 - y1 * a0;
+    const double b0 = cx - hand_depth * a0, b1 = cy - hand_depth * a1, b2 = cz - hand_depth * a2;
+    double* f = frames + (size_t)g * 12;
+    apply_t(T, b0, b1, b2, 1.0, f + 0);
+    apply_t(T, a0, a1, a2, 0.0, f + 3);
+    apply_t(T, y0, y1, y2, 0.0, f + 6);
+    apply_t(T, m0, m1, m2, 0.0, f + 9);
+}
+
+hipError_t launch_dataset_frames(const double* records, int stride, int G, const double* transform16, double hand_depth,
+                                 double* frames, hipStream_t s) {
+    if (!records || !frames || !transform16 || G < 1 || stride < 8) return hipErrorInvalidValue;
+    Transform4 T;
+    for (int i = 0; i < 16; ++i) T.m[i] = transform16[i];
+    hipLaunchKernelGGL(dataset_frames_kernel, dim3((G + 255) / 256), dim3(256), 0, s, records, stride, G, T, hand_depth,
+                       frames);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void crop_mask_kernel(const float* __restrict__ scene, int S,
                                                         const double* __restrict__ frames, int G,
                                                         CropLimits L, unsigned long long* __restrict__ mask,

@@ -174,19 +174,34 @@ struct GraspCells {
 __device__ __forceinline__ GraspCells grasp_cells(const double* __restrict__ f, const CropLimits& L,
                                                   const GridParams* __restrict__ gp) {
     GraspCells gc;
+    // World position of a gripper-frame corner q: origin + M^-1 q, with M the three frame rows.  The rows are
+    // orthonormal for the online crop (M^-1 = M^T), but frames given "as they are" (the training-data crop applies
+    // a view transform without re-normalising) may carry scale or shear, so the true inverse is used:
+    // M^-1 = [b x c | c x a | a x b] / det for rows a, b, c.
+    const double a0 = f[3], a1 = f[4], a2 = f[5], b0 = f[6], b1 = f[7], b2 = f[8], c0 = f[9], c1 = f[10], c2 = f[11];
+    const double u[3] = {b1 * c2 - b2 * c1, b2 * c0 - b0 * c2, b0 * c1 - b1 * c0};   // b x c
+    const double v[3] = {c1 * a2 - c2 * a1, c2 * a0 - c0 * a2, c0 * a1 - c1 * a0};   // c x a
+    const double w[3] = {a1 * b2 - a2 * b1, a2 * b0 - a0 * b2, a0 * b1 - a1 * b0};   // a x b
+    const double det = a0 * u[0] + a1 * u[1] + a2 * u[2];
+    const double inv_det = 1.0 / det;
+    const bool singular = !(fabs(det) > 1e-290) || !(fabs(inv_det) < 1e290);
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int k = 0; k < 8; ++k) {
         const double x = (k & 1) ? L.xhi : L.xlo, y = (k & 2) ? L.yhi : L.ylo, z = (k & 4) ? L.zhi : L.zlo;
         for (int c = 0; c < 3; ++c) {
-            const double w = f[c] + x * f[3 + c] + y * f[6 + c] + z * f[9 + c];
-            lo[c] = fmin(lo[c], w);
-            hi[c] = fmax(hi[c], w);
+            const double p = f[c] + (x * u[c] + y * v[c] + z * w[c]) * inv_det;
+            lo[c] = fmin(lo[c], p);
+            hi[c] = fmax(hi[c], p);
         }
     }
     for (int c = 0; c < 3; ++c) {
         const double margin = 1e-6 + 1e-9 * (fabs(lo[c]) + fabs(hi[c]));
         gc.c0[c] = cell_coord(lo[c] - margin, gp->origin[c], gp->inv_cell, gp->dim[c]);
         gc.c1[c] = cell_coord(hi[c] + margin, gp->origin[c], gp->inv_cell, gp->dim[c]);
+        if (singular || !(lo[c] <= hi[c])) {            // rows that span no volume (or NaN): visit every cell
+            gc.c0[c] = 0;
+            gc.c1[c] = gp->dim[c] - 1;
+        }
     }
     const double cell = 1.0 / gp->inv_cell;
     const double half_diag = 0.8660254037844387 * cell * (1.0 + 1e-6) + 1e-6;   // + rounding of the cell assignment

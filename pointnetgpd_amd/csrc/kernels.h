@@ -96,6 +96,9 @@ hipError_t launch_crop_gather_fused(const float* scene, int S, const double* fra
                                     int first_grasp_id, float* pts_out, unsigned char* valid, int* cnt, int* overflow,
                                     hipStream_t s);
 hipError_t launch_crop_frames(const double* grasps, double* frames, int G, hipStream_t s);
+// frames [G,12] of training-data grasp records [G,stride] (centre, axis, width, angle, ...) under a 4x4 transform
+hipError_t launch_dataset_frames(const double* records, int stride, int G, const double* transform16, double hand_depth,
+                                 double* frames, hipStream_t s);
 
 // PNGPD_CROP_BRUTE=1 in the environment selects the all-pairs pass with its [G, S/64] bit mask (the tests
 // cross-check the culled pass against it); the mask is part of the workspace only then.

@@ -6,11 +6,9 @@ view, crops the view's cloud with the same six planes as the online crop, and `_
 (:1098-1131) resamples the crop to N points and labels it from the grasp's score.  The reference
 does this per sample in 32 numpy worker processes (main_1v.py:158).
 
-Here the frames of all grasps of one (object, view) are built on the host with the reference's own
-scalar numpy operations (a few hundred flops per grasp; keeping them literally the same keeps the
-frames bit-identical), and the per-point work -- the crop of the cloud by every grasp and the
-resampling -- runs on the GPU: `pngpd_crop_count_frames`, `pngpd_crop_emit`,
-`pngpd_crop_gather_dataset`.  The six box limits are explicit for the same reason as in
+Here everything runs on the GPU: `pngpd_dataset_frames` builds the frames of all grasp records of one
+(object, view), `pngpd_crop_count_frames` / `pngpd_crop_emit` crop the cloud by every frame and
+`pngpd_crop_gather_dataset` resamples.  The six box limits are explicit for the same reason as in
 pointnetgpd_amd.crop (the corner table comes from dex-net).
 """
 from __future__ import annotations
@@ -27,47 +25,30 @@ from .crop import CropResult, _ptr
 MIN_POINT_LIMIT = 50      # model/dataset.py: self.min_point_limit
 
 
-def grasp_frame_from_config(grasp, transform, hand_depth):
-    """(bottom_ [3], matrix [3,3]) of model/dataset.py:776-835 for one grasp record; float64."""
-    grasp = np.asarray(grasp, dtype=np.float64)
-    transform = np.asarray(transform, dtype=np.float64)
-    center = grasp[0:3]
-    axis = grasp[3:6]
-    angle = grasp[7]
-    axis = axis / np.linalg.norm(axis)
-    binormal = axis
-    cos_t = np.cos(angle)
-    sin_t = np.sin(angle)
-    R1 = np.c_[[cos_t, 0, sin_t], [0, 1, 0], [-sin_t, 0, cos_t]]
-    axis_y = axis
-    axis_x = np.array([axis_y[1], -axis_y[0], 0])
-    if np.linalg.norm(axis_x) == 0:
-        axis_x = np.array([1, 0, 0])
-    axis_x = axis_x / np.linalg.norm(axis_x)
-    axis_y = axis_y / np.linalg.norm(axis_y)
-    axis_z = np.cross(axis_x, axis_y)
-    R2 = np.c_[axis_x, np.c_[axis_y, axis_z]]
-    approach = R2.dot(R1)[:, 0]
-    approach = approach / np.linalg.norm(approach)
-    minor_normal = np.cross(axis, approach)
-    bottom = center - hand_depth * approach
-    bottom_ = (np.dot(transform, np.array([bottom[0], bottom[1], bottom[2], 1]).T))[:3]
-    binormal_ = (np.dot(transform, np.array([binormal[0], binormal[1], binormal[2], 0])))[:3].reshape(3, 1)
-    approach_ = (np.dot(transform, np.array([approach[0], approach[1], approach[2], 0])))[:3].reshape(3, 1)
-    minor_normal_ = (np.dot(transform, np.array([minor_normal[0], minor_normal[1], minor_normal[2], 0])))[:3].reshape(3, 1)
-    matrix = np.hstack([approach_, binormal_, minor_normal_]).T
-    return bottom_, matrix
-
-
-def frames_from_configs(grasps, transform, hand_depth) -> np.ndarray:
-    """[G,12] float64: bottom_ followed by the rows of `matrix`, one row per grasp record."""
-    grasps = np.asarray(grasps, dtype=np.float64)
-    out = np.empty((len(grasps), 12), dtype=np.float64)
-    for g, rec in enumerate(grasps):
-        b, m = grasp_frame_from_config(rec, transform, hand_depth)
-        out[g, :3] = b
-        out[g, 3:] = m.reshape(9)
-    return out
+def frames_from_configs(grasps, transform, hand_depth, device=None) -> torch.Tensor:
+    """Frames float64 [G,12] on the device (origin `bottom_`, then the rows approach_, binormal_, minor_normal_ of
+    `matrix`; model/dataset.py:776-835) for grasp records [G, >=8] (centre, axis, width, angle, ...)."""
+    lib = _lib.load()
+    if isinstance(grasps, torch.Tensor) and grasps.is_cuda:
+        dev = grasps.device
+    else:
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    rec = torch.as_tensor(grasps, dtype=torch.float64, device=dev)
+    if rec.dim() == 1:
+        rec = rec[None]
+    if rec.dim() != 2 or rec.shape[1] < 8 or rec.shape[0] < 1:
+        raise ValueError(f"grasp records must be [G, >=8], got {tuple(rec.shape)}")
+    rec = rec.contiguous()
+    T = np.ascontiguousarray(np.asarray(transform, dtype=np.float64))
+    if T.shape != (4, 4):
+        raise ValueError(f"transform must be 4x4, got {T.shape}")
+    G = rec.shape[0]
+    frames = torch.empty((G, 12), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.pngpd_dataset_frames(_ptr(rec), G, rec.shape[1], T.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                            float(hand_depth), _ptr(frames), stream))
+    return frames
 
 
 def labels_from_scores(grasps, thresh_good, thresh_bad) -> np.ndarray:
@@ -85,7 +66,10 @@ def collect_pc_frames(frames, pc, limits, return_points=True) -> CropResult:
         raise RuntimeError("pointnetgpd_amd.dataset_crop runs on the GPU only; got a CPU tensor")
     dev = pc.device if isinstance(pc, torch.Tensor) else torch.device("cuda", torch.cuda.current_device())
     scene = torch.as_tensor(pc, dtype=torch.float32, device=dev).contiguous()
-    fr = torch.as_tensor(np.asarray(frames, dtype=np.float64).reshape(-1, 12), device=dev).contiguous()
+    if isinstance(frames, torch.Tensor):
+        fr = frames.to(device=dev, dtype=torch.float64).reshape(-1, 12).contiguous()
+    else:
+        fr = torch.as_tensor(np.asarray(frames, dtype=np.float64).reshape(-1, 12), device=dev).contiguous()
     if scene.dim() != 2 or scene.shape[1] != 3:
         raise ValueError("pc must be [S,3]")
     S, G = scene.shape[0], fr.shape[0]
@@ -144,7 +128,8 @@ def make_training_batch(grasps, pc, transform, limits, hand_depth, num_points, t
     """All samples one (object, view) pair yields: what __getitem__ returns for each grasp record,
     stacked; records whose crop is too small or whose score lies between the thresholds are dropped
     (the reference's collate function drops the None items, main_1v.py:127-129)."""
-    frames = frames_from_configs(grasps, transform, hand_depth)
+    dev = pc.device if isinstance(pc, torch.Tensor) else None
+    frames = frames_from_configs(grasps, transform, hand_depth, device=dev)
     labels = labels_from_scores(grasps, thresh_good, thresh_bad)
     crop = collect_pc_frames(frames, pc, limits, return_points=False)
     data, valid = resample(crop, num_points, seed=seed, min_point_limit=min_point_limit)

@@ -93,6 +93,12 @@ def test_crop_rejects_bad_calls():
     assert lib.pngpd_crop_subsample(vp(scene), S, vp(grasps), G, lim, vp(ws), nbytes, 3, 8, 20, 0, 0, vp(pts), vp(valid),
                                     vp(cnt), None, st) == ERR_INVALID
     assert lib.pngpd_vote(vp(cnt), vp(cnt), None, G, 3, 1, vp(cnt), vp(cnt), st) == ERR_SHAPE
+    rec = torch.zeros((G, 10), dtype=torch.float64, device="cuda")
+    frames = torch.empty((G, 12), dtype=torch.float64, device="cuda")
+    T = (ctypes.c_double * 16)(*([0.0] * 16))
+    assert lib.pngpd_dataset_frames(vp(rec), G, 7, T, 0.06, vp(frames), st) == ERR_SHAPE and "8 fields" in last_error(lib)
+    assert lib.pngpd_dataset_frames(vp(rec), G, 10, None, 0.06, vp(frames), st) == ERR_INVALID
+    assert lib.pngpd_dataset_frames(vp(rec), G, 10, T, 0.06, vp(frames), st) == _lib.OK
 
 
 def test_training_rejects_bad_calls():

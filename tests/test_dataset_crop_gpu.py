@@ -1,7 +1,8 @@
 """GPU parity of the training-data crop (pngpd_crop_count_frames / _emit / _gather_dataset through the
 C ABI) against the restatement of collect_pc_ + __getitem__ (model/dataset.py:767-924, 1098-1131):
-index sets and gripper-frame float64 coordinates bit-exact, resampled float32 input bit-exact for
-given draws.  The restatement is unpinned (the reference module needs pcl/dexnet and YCB data)."""
+index sets and gripper-frame float64 coordinates bit-exact for given frames, resampled float32 input bit-exact
+for given draws; the frames the device builds from grasp records (pngpd_dataset_frames) within a stated bound of
+the restatement's.  The restatement is unpinned (the reference module needs pcl/dexnet and YCB data)."""
 import numpy as np
 import pytest
 import torch
@@ -25,8 +26,51 @@ def _setup(seed, S, G):
     grasps, T, pc = synth.dataset_view(seed, S, G)
     hp = _hp()
     limits = hc.box_limits_from_hand_points(hp)
-    frames = dc.frames_from_configs(grasps, T, HD)
+    frames = do.frames_of_records(grasps, T, HD)        # the restatement's frames: the per-point tests start from them
     return grasps, T, pc, hp, limits, frames
+
+
+# The device evaluates the frame arithmetic in its own order and with its own sin / cos; entries are O(1).
+FRAME_TOL = 8 * np.finfo(np.float64).eps
+
+
+def test_device_frames_match_the_restatement():
+    for seed, G, stride in ((11, 64, 10), (15, 1000, 10), (16, 7, 8)):
+        grasps, T, pc = synth.dataset_view(seed, 1000, G)
+        T = T.copy()
+        if seed == 15:
+            T[:3, :3] *= 1.5                              # a transform with scale: the axes are not re-normalised
+        want = do.frames_of_records(grasps, T, HD)
+        got = dc.frames_from_configs(grasps[:, :stride], T, HD).cpu().numpy()
+        assert got.shape == want.shape
+        err = np.abs(got - want).max()
+        assert err <= FRAME_TOL * max(1.0, np.abs(want).max()), err
+    # the axis-along-z record takes the (1,0,0) branch (model/dataset.py:798-799)
+    assert abs(grasps[0, 3]) + abs(grasps[0, 4]) == 0.0
+
+
+def test_crop_from_device_built_frames_equals_the_restatement():
+    """Records -> frames -> crop entirely on the device: same index sets as collect_pc_ on this seeded view (no
+    point of it lies within 1e-12 of a plane, checked below, so a last-place difference in a frame cannot move it)."""
+    grasps, T, pc = synth.dataset_view(11, 200_000, 64)
+    hp = _hp()
+    limits = hc.box_limits_from_hand_points(hp)
+    frames = dc.frames_from_configs(grasps, T, HD)
+    res = dc.collect_pc_frames(frames, torch.from_numpy(pc).cuda(), limits)
+    idx, pts = res.index_lists(), res.point_lists()
+    total = 0
+    for g in range(len(grasps)):
+        b, m = do.frame_of_record(grasps[g], T, HD)
+        pg = np.dot(m, (pc - b).T).T
+        margin = np.min(np.abs(np.stack([pg[:, 1] - limits[0], pg[:, 1] - limits[1], pg[:, 2] - limits[2],
+                                         pg[:, 2] - limits[3], pg[:, 0] - limits[4], pg[:, 0] - limits[5]])))
+        assert margin > 1e-12
+        ind, gpc = do.collect_pc_(grasps[g], pc, T, HD, hp, min_point_limit=0)
+        np.testing.assert_array_equal(idx[g], ind)
+        if len(ind):
+            assert np.abs(pts[g] - pg[ind]).max() <= 1e-14
+        total += len(ind)
+    assert total > 1000
 
 
 def test_index_sets_and_points_bit_exact():
@@ -42,6 +86,29 @@ def test_index_sets_and_points_bit_exact():
         np.testing.assert_array_equal(pts[g], want)
         nonempty += len(ind) > 0
     assert nonempty > 32
+
+
+def test_frames_with_scale_and_shear_are_cropped_like_the_restatement():
+    """collect_pc_ applies the view transform to the axes without re-normalising them (model/dataset.py:831-835): under
+    a transform that shrinks and shears, the region is larger in the view than its nominal size and no longer a
+    rectangular box.  The culled traversal must still find every point the all-pairs arithmetic finds."""
+    grasps, T, pc = synth.dataset_view(17, 150_000, 48)
+    A = np.array([[0.6, 0.15, 0.0], [0.0, 0.55, -0.1], [0.05, 0.0, 0.7]])
+    T = T.copy()
+    T[:3, :3] = A @ T[:3, :3]
+    hp = _hp()
+    limits = hc.box_limits_from_hand_points(hp)
+    frames = do.frames_of_records(grasps, T, HD)
+    res = dc.collect_pc_frames(frames, torch.from_numpy(pc).cuda(), limits)
+    idx, pts = res.index_lists(), res.point_lists()
+    total = 0
+    for g in range(len(grasps)):
+        ind, _ = do.collect_pc_(grasps[g], pc, T, HD, hp, min_point_limit=0)
+        np.testing.assert_array_equal(idx[g], ind)
+        m = frames[g, 3:].reshape(3, 3)
+        np.testing.assert_array_equal(pts[g], (np.dot(m, (pc - frames[g, :3]).T)).T[ind])
+        total += len(ind)
+    assert total > 2000
 
 
 def test_resample_replays_given_draws_and_min_point_limit():

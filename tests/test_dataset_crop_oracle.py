@@ -1,5 +1,5 @@
 """CPU checks of the training-data crop restatement (oracle/dataset_crop_oracle.py) on a case that
-can be verified by hand, and of the host-side frame / label helpers of the product mirror."""
+can be verified by hand, and of the host-side label helper of the product mirror."""
 import numpy as np
 
 from oracle import crop_oracle as co
@@ -26,10 +26,27 @@ def test_axis_aligned_grasp_identity_transform():
     np.testing.assert_allclose(pts[0], [0.03, 0.0, 0.0], atol=1e-9)
 
 
-def test_frames_match_the_restatement_bit_for_bit():
+def test_frames_are_rigid_images_of_an_orthonormal_frame():
+    """The frame of a record, independent of how it is computed: orthonormal rows with the closing axis second and
+    right-handed; the origin lies hand_depth behind the contact centre along the approach row, in the view."""
+    grasps, T, pc = synth.dataset_view(3, 2000, 12)
+    frames = do.frames_of_records(grasps, T, 0.06)
+    for g in range(len(grasps)):
+        m = frames[g, 3:].reshape(3, 3)
+        np.testing.assert_allclose(m @ m.T, np.eye(3), atol=1e-14)          # T is rigid here
+        np.testing.assert_allclose(np.cross(m[0], m[1]), -m[2], atol=1e-14)  # minor = binormal x approach
+        axis = grasps[g, 3:6] / np.linalg.norm(grasps[g, 3:6])
+        np.testing.assert_allclose(m[1], T[:3, :3] @ axis, atol=1e-14)
+        centre_view = T[:3, :3] @ grasps[g, :3] + T[:3, 3]
+        np.testing.assert_allclose(frames[g, :3], centre_view - 0.06 * m[0], atol=1e-14)
+    # the record with its axis along z takes the (1,0,0) branch of :798-799
+    assert abs(grasps[0, 3]) + abs(grasps[0, 4]) == 0.0
+
+
+def test_frames_of_records_is_the_frame_collect_pc_uses():
     grasps, T, pc = synth.dataset_view(3, 2000, 12)
     hp = _hand_points()
-    frames = dc.frames_from_configs(grasps, T, 0.06)
+    frames = do.frames_of_records(grasps, T, 0.06)
     for g in range(len(grasps)):
         ind, pts = do.collect_pc_(grasps[g], pc, T, 0.06, hp, min_point_limit=0)
         m = frames[g, 3:].reshape(3, 3)
