@@ -311,8 +311,23 @@ int pngpd_train_backward(int B, int P, int k, const float* x_dev, const float* c
                          const float* dlogp_dev, const float* dtrans_dev, void* workspace_dev,
                          size_t workspace_bytes, void* stream);
 
+/*
+ * The same backward pass in up to three calls, for a data-parallel caller that reduces the gradients of one part
+ * over the ranks while the next part is still being computed (the capability nn.DataParallel provides at
+ * main_1v.py:224, reduce_add of the replicas' gradients).  `parts` is a mask of PNGPD_PART_*; the parts of one
+ * mask run in the order HEAD, TRUNK, STN, and successive calls must keep that order because each part consumes the
+ * input gradient the one before left in the workspace.  After a call returns, the gradients of its parts (HEAD:
+ * units FC1..FC3; TRUNK: FEAT_CONV1..3; STN: STN_CONV1..STN_FC3) are final in stream order.  HEAD | TRUNK | STN in
+ * one call is pngpd_train_backward.
+ */
+int pngpd_train_backward_part(int B, int P, int k, const float* x_dev, const float* const* params_dev,
+                              float* const* grads_dev, int n_slots, const float* logp_dev,
+                              const float* dlogp_dev, const float* dtrans_dev, void* workspace_dev,
+                              size_t workspace_bytes, int parts, void* stream);
+
 /* F.nll_loss(logp, target) with mean reduction (main_1v.py:270): loss_dev[1] and its gradient
- * dlogp_dev [B,k].  target_dev int64 [B]. */
+ * dlogp_dev [B,k].  target_dev int64 [B].  A label outside [0,k), on which F.nll_loss raises, is not used as an
+ * index: the loss comes out NaN and that sample contributes no gradient. */
 int pngpd_nll_loss(const float* logp_dev, const int64_t* target_dev, int B, int k, float* loss_dev,
                    float* dlogp_dev, void* stream);
 

@@ -794,8 +794,12 @@ __global__ void k_nll_loss(const float* __restrict__ logp, const long long* __re
     __shared__ float s[256];
     float acc = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
-        const int t = (int)target[b];
-        acc -= logp[(size_t)b * k + t];
+        // a label outside [0, k) (F.nll_loss raises on it) is never used as an index: the loss becomes NaN, which
+        // the caller sees without a separate flag, and that row gets no gradient
+        const long long tl = target[b];
+        const bool ok = tl >= 0 && tl < k;
+        const int t = ok ? (int)tl : -1;
+        acc -= ok ? logp[(size_t)b * k + t] : __int_as_float(0x7fc00000);
         for (int j = 0; j < k; ++j) dlogp[(size_t)b * k + j] = (j == t) ? -1.0f / B : 0.f;
     }
     s[threadIdx.x] = acc;

@@ -334,26 +334,53 @@ int pngpd_train_saved(int B, int P, int k, const void* workspace_dev, size_t wor
     return PNGPD_OK;
 }
 
-int pngpd_train_backward(int B, int P, int k, const float* x_dev, const float* const* params_dev,
-                         float* const* grads_dev, int n_slots, const float* logp_dev, const float* dlogp_dev,
-                         const float* dtrans_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+// Backward in the order the gradients become final: head, trunk, transform regressor (STN).
+static int train_backward_impl(int B, int P, int k, const float* x_dev, const float* const* params_dev,
+                               float* const* grads_dev, int n_slots, const float* logp_dev, const float* dlogp_dev,
+                               const float* dtrans_dev, void* workspace_dev, size_t workspace_bytes, int parts,
+                               void* stream) {
     if (!x_dev || !params_dev || !grads_dev || !logp_dev || !dlogp_dev)
         return fail(PNGPD_ERR_INVALID, "pngpd_train_backward: NULL argument");
     if (n_slots != PNGPD_SLOTS) return fail(PNGPD_ERR_INVALID, "training table must have %d slots", PNGPD_SLOTS);
+    const int all = PNGPD_PART_STN | PNGPD_PART_TRUNK | PNGPD_PART_HEAD;
+    if (parts == 0 || (parts & ~all)) return fail(PNGPD_ERR_INVALID, "pngpd_train_backward_part: bad part mask %d", parts);
     int rc = check_shape(B, P, k, workspace_dev, workspace_bytes);
     if (rc) return rc;
     if ((rc = check_tables((float* const*)params_dev, false))) return rc;
     if ((rc = check_tables(grads_dev, false))) return rc;
     hipStream_t s = (hipStream_t)stream;
     TrainWs W(workspace_dev, B, P, k);
-    HIP_TRY(pngpd::t_logsoftmax_bwd(logp_dev, dlogp_dev, W.dlogits, B, k, s));
-    if ((rc = bwd_fc(W.head_fc, params_dev, grads_dev, PNGPD_U_FC1, W.trunk.pooled, W.dlogits, B, k, W, s))) return rc;
-    if ((rc = bwd_stack(W.trunk, params_dev, grads_dev, PNGPD_U_FEAT_CONV1, W.head_fc.din, B, P, 0, true, W, s)))
-        return rc;
-    HIP_TRY(pngpd::t_trans_grad(x_dev, W.trunk.dX3, B, P, dtrans_dev, W.dtrans, s));
-    if ((rc = bwd_fc(W.stn_fc, params_dev, grads_dev, PNGPD_U_STN_FC1, W.stn.pooled, W.dtrans, B, 9, W, s))) return rc;
-    if ((rc = bwd_stack(W.stn, params_dev, grads_dev, PNGPD_U_STN_CONV1, W.stn_fc.din, B, P, 1, false, W, s))) return rc;
+    if (parts & PNGPD_PART_HEAD) {
+        HIP_TRY(pngpd::t_logsoftmax_bwd(logp_dev, dlogp_dev, W.dlogits, B, k, s));
+        if ((rc = bwd_fc(W.head_fc, params_dev, grads_dev, PNGPD_U_FC1, W.trunk.pooled, W.dlogits, B, k, W, s))) return rc;
+    }
+    if (parts & PNGPD_PART_TRUNK) {
+        if ((rc = bwd_stack(W.trunk, params_dev, grads_dev, PNGPD_U_FEAT_CONV1, W.head_fc.din, B, P, 0, true, W, s)))
+            return rc;
+        HIP_TRY(pngpd::t_trans_grad(x_dev, W.trunk.dX3, B, P, dtrans_dev, W.dtrans, s));
+    }
+    if (parts & PNGPD_PART_STN) {
+        if ((rc = bwd_fc(W.stn_fc, params_dev, grads_dev, PNGPD_U_STN_FC1, W.stn.pooled, W.dtrans, B, 9, W, s))) return rc;
+        if ((rc = bwd_stack(W.stn, params_dev, grads_dev, PNGPD_U_STN_CONV1, W.stn_fc.din, B, P, 1, false, W, s)))
+            return rc;
+    }
     return PNGPD_OK;
+}
+
+int pngpd_train_backward(int B, int P, int k, const float* x_dev, const float* const* params_dev,
+                         float* const* grads_dev, int n_slots, const float* logp_dev, const float* dlogp_dev,
+                         const float* dtrans_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+    return train_backward_impl(B, P, k, x_dev, params_dev, grads_dev, n_slots, logp_dev, dlogp_dev, dtrans_dev,
+                               workspace_dev, workspace_bytes, PNGPD_PART_STN | PNGPD_PART_TRUNK | PNGPD_PART_HEAD,
+                               stream);
+}
+
+int pngpd_train_backward_part(int B, int P, int k, const float* x_dev, const float* const* params_dev,
+                              float* const* grads_dev, int n_slots, const float* logp_dev, const float* dlogp_dev,
+                              const float* dtrans_dev, void* workspace_dev, size_t workspace_bytes, int parts,
+                              void* stream) {
+    return train_backward_impl(B, P, k, x_dev, params_dev, grads_dev, n_slots, logp_dev, dlogp_dev, dtrans_dev,
+                               workspace_dev, workspace_bytes, parts, stream);
 }
 
 int pngpd_nll_loss(const float* logp_dev, const int64_t* target_dev, int B, int k, float* loss_dev, float* dlogp_dev,

@@ -27,6 +27,16 @@ def world():
     return 0, 1
 
 
+def broadcast_int(value: int, device=None, src: int = 0) -> int:
+    """`value` of rank `src` on every rank (the value itself when no process group is up)."""
+    if world()[1] == 1:
+        return int(value)
+    on_device = dist.get_backend() == "nccl"
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device if on_device else "cpu")
+    dist.broadcast(t, src=src)
+    return int(t.item())
+
+
 def gather_concat(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """Concatenate per-rank result slices (ragged along dim 0) on every rank, in rank order."""
     rank, ws = world()
@@ -36,9 +46,12 @@ def gather_concat(local: torch.Tensor, n_total: int) -> torch.Tensor:
     width = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(bufs, pad)
-    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+    staged = pad.is_cuda and dist.get_backend() != "nccl"      # a host-memory backend (gloo): stage through the host
+    send = pad.cpu() if staged else pad
+    bufs = [torch.empty_like(send) for _ in range(ws)]
+    dist.all_gather(bufs, send)
+    out = torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+    return out.to(local.device) if staged else out
 
 
 def score_grasps_sharded(model, scene, grasps, limits, repeat: int = 3, seed: int = 0, gather: bool = True):

@@ -19,8 +19,10 @@ What is not reproduced: PointGraspOneViewDataset (it needs dex-net, autolab_core
 __getitem__ returns, model/dataset.py:1128-1131) or on a seeded synthetic set; `dataset_crop.make_training_batch`
 produces such arrays from raw clouds and grasp configurations on the GPU.
 
-Several GPUs: one process per GPU (torchrun); every rank takes its contiguous share of each epoch's permutation
-and `Trainer` all-reduces the gradient bucket.
+Several GPUs: one process per GPU (torchrun).  Every rank takes an EQUAL contiguous share of each epoch's
+permutation (the n mod world samples left over sit the epoch out), so all ranks run the same number of steps with
+the same batch sizes - a rank with one step more would wait for ever in its gradient all-reduce; the permutation
+seed is rank 0's, and `Trainer` starts every rank from rank 0's weights and all-reduces the gradients.
 """
 from __future__ import annotations
 
@@ -90,17 +92,20 @@ class EpochLoader:
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
         self.seed, self.rank, self.world, self.epoch = seed, rank, world, 0
 
+    def _share(self):
+        """Samples per rank and epoch: the same number on every rank."""
+        return len(self.dataset) // self.world
+
     def __len__(self):
-        n = _dist.shard_range(len(self.dataset), self.rank, self.world)
-        n = n[1] - n[0]
+        n = self._share()
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
     def __iter__(self):
         n = len(self.dataset)
         order = np.random.default_rng(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
         self.epoch += 1
-        lo, hi = _dist.shard_range(n, self.rank, self.world)
-        order = order[lo:hi]
+        share = self._share()
+        order = order[self.rank * share:(self.rank + 1) * share]
         ds = self.dataset
         for i in range(len(self)):
             idx = order[i * self.batch_size:(i + 1) * self.batch_size]
@@ -120,9 +125,13 @@ def train_epoch(model, loader, trainer, epoch, base_lr=0.005, log_interval=10, l
     correct = 0
     dataset_size = 0
     batch_size = getattr(loader, "batch_size", None) or 1
+    k = model.fc3.out_features
     for batch_idx, (data, target) in enumerate(loader):
-        if len(data) <= 1:
+        if len(data) <= 1:            # the same on every rank: EpochLoader gives all ranks equal batch sizes
             continue
+        if int(target.min()) < 0 or int(target.max()) >= k:
+            raise ValueError(f"batch {batch_idx}: labels must lie in [0, {k}), got [{int(target.min())}, "
+                             f"{int(target.max())}] (F.nll_loss raises on such a target, main_1v.py:270)")
         dataset_size += data.shape[0]
         data, target = data.float().to(device), target.long().squeeze().to(device)
         loss, output = trainer.step(data, target)
@@ -223,10 +232,10 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(args.gpu)))
-    if world > 1 and not torch.distributed.is_initialized():
-        torch.distributed.init_process_group("nccl")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if world > 1 and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group(os.environ.get("PNGPD_DIST_BACKEND", "nccl"))
     torch.cuda.manual_seed(1)                                              # main_1v.py:78-79
 
     if args.synthetic:
@@ -257,8 +266,10 @@ def main(argv=None):
 
     current_time = time.strftime("%Y-%m-%dT%H:%M", time.localtime())
     logger = ScalarLog(os.path.join(args.log_dir, current_time)) if rank == 0 else None
+    # one shuffle seed for all ranks (rank 0's clock): with different seeds the ranks' shares would overlap
+    seed = _dist.broadcast_int(int(time.time()) if not args.synthetic else 0, device)
     train_loader = EpochLoader(ArrayDataset(*train_arrays), args.batch_size, shuffle=True, drop_last=True,
-                               seed=int(time.time()) if not args.synthetic else 0, rank=rank, world=world)
+                               seed=seed, rank=rank, world=world)
     trainer = Trainer(model, lr=args.lr)
     acc = loss = None
     for epoch_i in range(int(is_resume) * args.load_epoch, args.epoch):

@@ -7,9 +7,13 @@ Two ways in, same kernels:
   pngpd_train_backward; ``F.nll_loss(output, target).backward()`` and ``torch.optim.Adam`` work
   unchanged (main_1v.py:266-274).
 * fused: `Trainer.step(data, target)` keeps all parameters, gradients and Adam moments in flat
-  buffers, runs forward, NLL, backward, ONE all-reduce of the flat gradient bucket over RCCL when
-  several ranks train data-parallel, and a fused Adam update.  BatchNorm statistics stay
-  per-replica, like nn.DataParallel in the reference (main_1v.py:224).
+  buffers, runs forward, NLL, backward and a fused Adam update.  When several ranks train
+  data-parallel the flat gradient buffer is reduced over RCCL in three buckets - head, trunk,
+  transform regressor, the order in which the backward pass finishes them - each started as soon as
+  its part of the backward has been queued, so the exchange of one bucket runs under the kernels of the
+  next part.  Every rank starts from rank 0's weights and BatchNorm buffers (broadcast when the Trainer
+  is built); BatchNorm statistics then stay per-replica, like nn.DataParallel in the reference
+  (main_1v.py:224).
 """
 from __future__ import annotations
 
@@ -124,8 +128,12 @@ def saved_activation(ws, B, P, k, name):
     return flat.view(rows, count.value // rows)
 
 
-def train_backward(model, x, logp, dlogp, dtrans, ws, grad_of):
-    """Backward of train_forward.  grad_of(param) -> tensor that receives that parameter's gradient."""
+PARTS_ALL = _lib.PART_STN | _lib.PART_TRUNK | _lib.PART_HEAD
+
+
+def train_backward(model, x, logp, dlogp, dtrans, ws, grad_of, parts=PARTS_ALL):
+    """Backward of train_forward.  grad_of(param) -> tensor that receives that parameter's gradient.
+    `parts` (mask of _lib.PART_*) runs a segment only; segments must follow each other as HEAD, TRUNK, STN."""
     lib = _lib.load()
     B, _, P = x.shape
     k = model.fc3.out_features
@@ -139,9 +147,9 @@ def train_backward(model, x, logp, dlogp, dtrans, ws, grad_of):
         dtrans_p = ctypes.c_void_p(dtrans.data_ptr())
     with torch.cuda.device(x.device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        _lib.check(lib.pngpd_train_backward(B, P, k, ctypes.c_void_p(x.data_ptr()), params, grads, _lib.SLOTS,
-                                            ctypes.c_void_p(logp.data_ptr()), ctypes.c_void_p(dlogp.data_ptr()),
-                                            dtrans_p, ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream))
+        _lib.check(lib.pngpd_train_backward_part(B, P, k, ctypes.c_void_p(x.data_ptr()), params, grads, _lib.SLOTS,
+                                                 ctypes.c_void_p(logp.data_ptr()), ctypes.c_void_p(dlogp.data_ptr()),
+                                                 dtrans_p, ctypes.c_void_p(ws.data_ptr()), ws.numel(), parts, stream))
 
 
 class TrainFunction(torch.autograd.Function):
@@ -197,7 +205,8 @@ class Trainer:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.group = process_group
         self.step_count = 0
-        self.params = [p for p in model.parameters()]
+        named = list(model.named_parameters())
+        self.params = [p for _, p in named]
         dev = self.params[0].device
         if dev.type != "cuda":
             raise RuntimeError("move the model to a ROCm device before building a Trainer")
@@ -208,39 +217,93 @@ class Trainer:
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
         self._gview = {}
-        for p in self.params:
+        owner = []                 # which part of the network every parameter belongs to, in flat order
+        for name, p in named:
             k = p.numel()
             self.flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + k].view_as(p)         # parameters become views of the bucket
             g = self.flat_g[off:off + k].view_as(p)
             p.grad = g
             self._gview[id(p)] = g
+            part = _lib.PART_STN if name.startswith("feat.stn.") else (
+                _lib.PART_TRUNK if name.startswith("feat.") else _lib.PART_HEAD)
+            owner.append((part, off, off + k))
             off += k
+        # One contiguous range of the flat gradient per part (registration order is STN, trunk, head), listed in the
+        # order the backward pass finishes them.
+        self.buckets = []
+        for part in (_lib.PART_HEAD, _lib.PART_TRUNK, _lib.PART_STN):
+            spans = [(lo, hi) for q, lo, hi in owner if q == part]
+            lo, hi = spans[0][0], spans[-1][1]
+            if sum(b - a for a, b in spans) != hi - lo:
+                raise RuntimeError("parameters of one network part are not contiguous in registration order")
+            self.buckets.append((part, lo, hi))
         self._ws = None
         self.conv3_ms = None      # set to a list to collect the conv3 kernel durations of every step
+        if self.world_size() > 1:
+            self.broadcast_state()
 
     def world_size(self):
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.group)
         return 1
 
-    def step(self, data, target):
-        """One training step; returns (loss[1] tensor, logp[B,k])."""
+    def _device_collectives(self):
+        return dist.get_backend(self.group) == "nccl"
+
+    def broadcast_state(self, src=0):
+        """Every rank takes rank `src`'s parameters and BatchNorm buffers (running statistics and batch counters):
+        replicas built from different random initialisations would otherwise apply averaged gradients to different
+        weights and never agree."""
+        tensors = [self.flat_p]
+        tensors += [b for m in self.model.modules() if isinstance(m, torch.nn.BatchNorm1d)
+                    for b in (m.running_mean, m.running_var, m.num_batches_tracked)]
+        for t in tensors:
+            if self._device_collectives():
+                dist.broadcast(t, src=src, group=self.group)
+            else:                      # a host-memory backend (gloo): stage through the host
+                host = t.detach().cpu()
+                dist.broadcast(host, src=src, group=self.group)
+                t.copy_(host)
+        invalidate_packed_weights()
+
+    def _reduce_bucket(self, lo, hi):
+        """Sum flat_g[lo:hi] over the ranks (Adam divides by the world size).  Returns a work handle to wait on, or
+        None when the exchange has already completed."""
+        g = self.flat_g[lo:hi]
+        if self._device_collectives():
+            # RCCL runs the collective on its own stream, ordered behind what is queued on the current stream so
+            # far; kernels queued afterwards overlap with it
+            return dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        host = g.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+        g.copy_(host)
+        return None
+
+    def gradients(self, data, target):
+        """Forward, loss and backward of one batch; leaves in flat_g the gradient SUMMED over the ranks.
+        Returns (loss[1] tensor of this rank's batch, logp[B,k])."""
         model = self.model
         if not model.training:
             raise RuntimeError("Trainer.step needs model.train()")
         logp, _, self._ws, x = train_forward(model, data, self._ws, self.conv3_ms)
         loss, dlogp = nll_loss(logp, target)
-        train_backward(model, x, logp, dlogp, None, self._ws, lambda p: self._gview[id(p)])
-        ws = self.world_size()
-        if ws > 1:
-            # the one collective of the path: the flat gradient bucket, summed (Adam divides by ws)
-            if dist.get_backend(self.group) == "nccl":
-                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
-            else:   # a host-memory backend (gloo): stage through the host
-                host = self.flat_g.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-                self.flat_g.copy_(host)
+        grad_of = lambda p: self._gview[id(p)]      # noqa: E731
+        if self.world_size() == 1:
+            train_backward(model, x, logp, dlogp, None, self._ws, grad_of)
+            return loss, logp
+        pending = []
+        for part, lo, hi in self.buckets:           # head, trunk, transform regressor
+            train_backward(model, x, logp, dlogp, None, self._ws, grad_of, parts=part)
+            pending.append(self._reduce_bucket(lo, hi))
+        for work in pending:
+            if work is not None:
+                work.wait()                         # the current stream waits for the collective's stream
+        return loss, logp
+
+    def apply(self, world=None):
+        """The Adam update from flat_g, which holds the sum of `world` ranks' gradients."""
+        world = self.world_size() if world is None else world
         self.step_count += 1
         lib = _lib.load()
         dev = self.flat_p.device
@@ -249,6 +312,11 @@ class Trainer:
             _lib.check(lib.pngpd_adam_step(ctypes.c_void_p(self.flat_p.data_ptr()), ctypes.c_void_p(self.flat_g.data_ptr()),
                                            ctypes.c_void_p(self.exp_avg.data_ptr()),
                                            ctypes.c_void_p(self.exp_avg_sq.data_ptr()), self.flat_p.numel(), self.lr,
-                                           self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / ws, stream))
+                                           self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / world, stream))
         invalidate_packed_weights()    # the fused update bypasses torch's version counters
+
+    def step(self, data, target):
+        """One training step; returns (loss[1] tensor, logp[B,k])."""
+        loss, logp = self.gradients(data, target)
+        self.apply()
         return loss, logp

@@ -167,6 +167,18 @@ def test_nll_loss_kernel():
     np.testing.assert_allclose(dlogp.cpu().numpy(), ref.grad.numpy(), atol=1e-7)
 
 
+def test_nll_loss_label_out_of_range_is_not_used_as_an_index():
+    """F.nll_loss raises on a target outside [0, k); the kernel must not read out of bounds: NaN loss, and the
+    offending row gets no gradient while the others keep theirs."""
+    logp = torch.log_softmax(torch.randn(8, 2, generator=torch.Generator().manual_seed(0)), 1).cuda()
+    for bad in (2, -1, 10 ** 12):
+        target = torch.tensor([0, 1, 1, bad, 0, 0, 1, 1], dtype=torch.int64).cuda()
+        loss, dlogp = nll_loss(logp, target)
+        assert torch.isnan(loss).all()
+        d = dlogp.cpu()
+        assert (d[3] == 0).all() and d[0, 0] == -1.0 / 8 and d[1, 1] == -1.0 / 8
+
+
 def test_batch_of_one_is_rejected_like_the_reference_skips_it():
     m = hip_train_model(750, 2, 1, 1.7)
     with pytest.raises(ValueError, match="more than one"):
