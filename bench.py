@@ -150,6 +150,9 @@ def online_workload(args, dev, rank, n_gpus, dist):
     model = model.to(dev).eval()
     model.precision = args.precision
     grasps_dev = torch.from_numpy(grasps).to(dev)
+    # synthetic weights call every grasp bad: centre the classifier so that the vote, the good-grasp filter and the
+    # ranking have real work (about half of the grasps come out good)
+    synth.balance_head(model, hc.crop_subsample(grasps_dev[:512], scene, limits, P, repeat=1, seed=1)[0])
 
     def step():
         return score_grasps(model, scene, grasps_dev, limits, repeat=R, seed=0)

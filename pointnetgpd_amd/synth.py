@@ -199,3 +199,20 @@ def dataset_view(seed: int, S: int, G: int, cube: float = 0.3):
     local = uniform(seed, "ds.cloud", (S, 3), 0.0, cube).astype(np.float64)
     pc = (local @ R.T + T[:3, 3]).astype(np.float32)
     return grasps, T, pc
+
+
+def balance_head(model, points) -> float:
+    """Shift the last classifier bias of a PointNetCls so that about half of `points` ([B,P,3] on the model's device)
+    land in the highest class.  Seeded synthetic weights put nearly every candidate into one class, which would leave
+    the vote, the good-grasp filter and the ranking of the online loop with nothing to do.  Returns the shift."""
+    import torch
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        logp = model.forward_points(points)[0]
+        k = logp.shape[1]
+        rest = logp[:, :k - 1].max(dim=1).values
+        shift = float((rest - logp[:, k - 1]).median())
+        model.fc3.bias[k - 1] += shift             # in place through autograd's counter: the packed weights are rebuilt
+    model.train(was_training)
+    return shift

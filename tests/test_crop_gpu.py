@@ -197,6 +197,65 @@ def test_full_size_scene_properties():
         np.testing.assert_array_equal(idx[off[g]:off[g + 1]], ref)
 
 
+def test_config5_online_scoring_at_full_size():
+    """S = 1,000,000 points x G = 10,000 grasps through online.score_grasps (crop + 3 draws + network + vote + rank)
+    with a classifier centred so that about half of the grasps are good: the one-pass crop + subsample equals the
+    three-call path for all 10,000 grasps bit for bit, the ranking is the descending stable sort of the good
+    grasps, and sampled grasps equal the oracle chain (C crop oracle -> the device's draws replayed by their host
+    twin -> eager float32 network -> softmax / arg-max -> vote)."""
+    from pointnetgpd_amd.online import score_grasps
+    S, G, P, k, R, seed = 1_000_000, 10_000, 750, 2, 3, 93
+    scene = synth.scene_points(seed, S, 0.5)
+    grasps = synth.random_grasps(seed, G, 0.5, 0.06)
+    scene_dev = torch.from_numpy(scene).cuda()
+    m = PointNetCls(P, 3, k)
+    m.load_state_dict(synth.torch_state_dict(seed, k, 0.02))
+    m = m.cuda().eval()
+    synth.balance_head(m, hc.crop_subsample(grasps[:512], scene_dev, LIMITS, P, repeat=1, seed=1)[0])
+    out = score_grasps(m, scene_dev, grasps, LIMITS, repeat=R, seed=5)
+    label, score, valid = out.label.cpu().numpy(), out.score.cpu().numpy(), out.valid.cpu().numpy()
+    n_valid, n_good = int(valid.sum()), int(((label == 1) & (valid != 0)).sum())
+    assert n_valid > 0.95 * G and 0.2 * n_valid < n_good < 0.8 * n_valid, (n_valid, n_good)
+    order = out.order.cpu().numpy()
+    assert set(order.tolist()) == set(np.nonzero((label == 1) & (valid != 0))[0].tolist())
+    assert (np.diff(score[order]) <= 0).all()
+    ties = np.nonzero(np.diff(score[order]) == 0)[0]
+    assert (order[ties] < order[ties + 1]).all()                       # stable: equal scores keep the grasp order
+    # one pass == three calls, every grasp
+    res = hc.collect_pc(grasps, scene_dev, LIMITS, return_points=False)
+    pts_ref, valid_ref = hc.subsample(res, P, repeat=R, seed=5)
+    pts, valid1, counts, overflow = hc.crop_subsample(grasps, scene_dev, LIMITS, P, repeat=R, seed=5)
+    assert int(overflow.item()) == 0
+    assert torch.equal(counts, res.counts) and torch.equal(valid1, valid_ref) and torch.equal(pts, pts_ref)
+    assert torch.equal(out.counts, res.counts) and torch.equal(out.valid, valid_ref)
+    # sampled grasps against the oracle chain
+    sd = {n: v.detach().cpu() for n, v in m.state_dict().items()}
+    oracle = po.build_cls(P, k, sd)
+    good, bad = order[:: max(1, len(order) // 10)][:10], np.nonzero((label == 0) & (valid != 0))[0][::97][:10]
+    pick = sorted(set(good.tolist() + bad.tolist() + [0, G - 1]))
+    idx_ref, pts_g_ref = co.crop_c(grasps[pick], scene, LIMITS)
+    cnt = res.counts.cpu().numpy()
+    checked = 0
+    for j, g in enumerate(pick):
+        assert len(idx_ref[j]) == cnt[g]
+        if cnt[g] < 20:
+            assert valid[g] == 0 and label[g] == 0 and score[g] == 0.0
+            continue
+        preds, prs = [], []
+        for r in range(R):
+            sel = hc.draw_selection(5, g, r, int(cnt[g]), P)
+            np.testing.assert_array_equal(pts[g * R + r].cpu().numpy(), pts_g_ref[j][sel].astype(np.float32))
+            p_, pr_ = po.oracle_test_network(oracle, co.subsample(pts_g_ref[j], sel))
+            preds.append(int(p_[0]))
+            prs.append(pr_)
+        l_ref, s_ref = co.vote(preds, prs, k)
+        if min(abs(float(pr[0, 0] - pr[0, 1])) for pr in prs) > 1e-3:
+            assert int(label[g]) == l_ref, g
+            assert abs(float(score[g]) - float(s_ref)) <= 1e-4, g
+            checked += 1
+    assert checked >= 12
+
+
 def test_online_pipeline_ranks_good_grasps():
     from pointnetgpd_amd.dist import score_grasps_sharded
     from pointnetgpd_amd.online import score_grasps

@@ -157,16 +157,16 @@ def test_weights_repacked_after_in_place_update():
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_full_size_properties(precision):
-    """B=4096 (bf16) / 512 (fp32), P=750: results do not depend on batch position, batch size or
+    """B=4096, P=750 in both arithmetic modes: results do not depend on batch position, batch size or
     on the order of the points inside a candidate (the max-pool is symmetric) - bit for bit."""
-    B = 4096 if precision == "bf16" else 512
+    B = 4096
     P, seed = 750, 41
     m = hip_model(P, 2, seed, 0.02, precision)
     x = torch.from_numpy(synth.candidate_points(seed, B, P, "gripper")).cuda()
     logp, trans = m(x)
     assert torch.isfinite(logp).all()
     assert torch.allclose(logp.exp().sum(1), torch.ones(B, device="cuda"), atol=1e-5)
-    idx = torch.tensor([0, 1, B // 2, B - 1], device="cuda")
+    idx = torch.tensor([0, 1, 255, 256, 1023, B // 2, B // 2 + 1, 3000, 3071, 3072, 4000, B - 2, B - 1], device="cuda")
     sub, sub_t = m(x[idx].contiguous())
     assert torch.equal(sub, logp[idx]) and torch.equal(sub_t, trans[idx])
     perm = torch.randperm(P, generator=torch.Generator().manual_seed(0)).cuda()

@@ -89,16 +89,16 @@ def test_fused_trainer_matches_autograd_path_and_oracle():
     target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) * k).astype(np.int64))
     sd0 = synth.torch_state_dict(seed, k, 1.0, gain)
 
-    def oracle_step(sd, moments):
-        oracle = po.build_cls(P, k, sd, eval_mode=False)
+    def oracle_step(sd, moments, dtype=torch.float32):
+        oracle = po.build_cls(P, k, sd, eval_mode=False).to(dtype)
         oopt = torch.optim.Adam(oracle.parameters(), lr=0.005)
         if moments is not None:
             for n, p in oracle.named_parameters():
                 m1, m2 = moments[n]
-                oopt.state[p] = {"step": torch.tensor(1.0), "exp_avg": m1.view_as(p).clone(),
-                                 "exp_avg_sq": m2.view_as(p).clone()}
+                oopt.state[p] = {"step": torch.tensor(1.0), "exp_avg": m1.view_as(p).clone().to(dtype),
+                                 "exp_avg_sq": m2.view_as(p).clone().to(dtype)}
         oopt.zero_grad()
-        out, _ = oracle(x)
+        out, _ = oracle(x.to(dtype))
         l = F.nll_loss(out, target)
         l.backward()
         grads = {n: p.grad.clone() for n, p in oracle.named_parameters()}
@@ -136,15 +136,47 @@ def test_fused_trainer_matches_autograd_path_and_oracle():
     loss = tr.step(x.cuda(), target.cuda())[0].item()
     assert abs(loss - loss_ref) < 2e-5
     compare(ref_sd, grads, 2e-5)
-    # step 2, from the HIP model's own state
+    # step 2, from the HIP model's own state, three ways: the fused trainer, the float32 oracle and the SAME oracle in
+    # float64 (parameters, running statistics and Adam moments converted exactly).  The float64 step is the arbiter:
+    # the trainer must be as close to it as the float32 oracle is, parameter by parameter (measured on MI355X: both
+    # within 1e-6 of it after Adam, gradients within 5e-6 of each tensor's largest entry).
     sd1 = {n: v.detach().cpu().clone() for n, v in m.state_dict().items()}
-    loss_ref, ref_sd, grads = oracle_step(sd1, hip_moments())
+    mom = hip_moments()
+    loss_ref, ref_sd, grads = oracle_step(sd1, mom)
+    loss64, ref64_sd, grads64 = oracle_step(sd1, mom, torch.float64)
     loss = tr.step(x.cuda(), target.cuda())[0].item()
-    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
-    # BatchNorm over these 6 samples amplifies float32 rounding: two correct float32 forward passes whose FC
-    # activations both sit within 1e-5 of a float64 evaluation give gradients that differ by up to 3e-4 of their
-    # largest entry (tests/diag_trainer_step2.py prints them per parameter), i.e. a few 1e-4 after Adam's scaling
-    compare(ref_sd, grads, 2e-4)
+    assert abs(loss - loss64) < 2e-5 * max(1.0, abs(loss64)) and abs(loss_ref - loss64) < 2e-5 * max(1.0, abs(loss64))
+    got_sd = m.state_dict()
+    report = []
+    for n, g64 in grads64.items():
+        clear = g64.abs() > 1e-4          # below that the Adam update is the sign of rounding noise
+        if not clear.any():
+            continue
+        e_hip = float((got_sd[n].cpu().double() - ref64_sd[n]).abs()[clear].max())
+        e_o32 = float((ref_sd[n].double() - ref64_sd[n]).abs()[clear].max())
+        report.append((n, e_hip, e_o32))
+    # gradients of the same step, relative to the largest entry of each tensor
+    gh, off = {}, 0
+    for n, p in m.named_parameters():
+        gh[n] = tr.flat_g[off:off + p.numel()].cpu().view_as(p).double()
+        off += p.numel()
+    worst_hip = worst_o32 = 0.0
+    for n, g64 in grads64.items():
+        scale = float(g64.abs().max())
+        if scale < 1e-5:
+            continue
+        worst_hip = max(worst_hip, float((gh[n] - g64).abs().max()) / scale)
+        worst_o32 = max(worst_o32, float((grads[n].double() - g64).abs().max()) / scale)
+    print(f"step 2 gradients vs float64, relative to each tensor's largest entry: trainer {worst_hip:.2e}, "
+          f"float32 oracle {worst_o32:.2e}")
+    for n, e_hip, e_o32 in report:
+        print(f"  {n:28s} post-Adam parameter error vs float64: trainer {e_hip:.2e}  float32 oracle {e_o32:.2e}")
+    assert worst_hip <= max(3.0 * worst_o32, 2e-5), (worst_hip, worst_o32)
+    for n, e_hip, e_o32 in report:
+        assert e_hip <= max(3.0 * e_o32, 2e-6) and e_hip < 5e-6, (n, e_hip, e_o32)
+    for n in ref_sd:
+        if n.endswith(("running_mean", "running_var")):
+            np.testing.assert_allclose(got_sd[n].cpu().numpy(), ref64_sd[n].numpy(), rtol=2e-4, atol=2e-5, err_msg=n)
     # eval after training must re-fold / re-pack the weights the fused update wrote: compare with the
     # oracle evaluated on the HIP model's OWN post-training state_dict
     m.eval()
@@ -320,7 +352,7 @@ def forced_forward(o, x, arg_stn, arg_trunk, masks):
 
 
 @pytest.mark.parametrize("P,B,k,seed", [(130, 70, 2, 8), (64, 70, 2, 8), (64, 70, 2, 13), (37, 150, 2, 9),
-                                        (300, 20, 3, 10), (750, 24, 2, 11)])
+                                        (300, 20, 3, 10), (750, 24, 2, 11), (750, 256, 2, 12)])
 def test_gradients_with_the_kernels_own_decisions(P, B, k, seed):
     """A PointNet step is piecewise smooth: the max over points and every ReLU switch where two values tie to within
     float32 rounding, and with ~10^6 such decisions per step a few always do.  Two correct float32 implementations
@@ -369,3 +401,45 @@ def test_gradients_with_the_kernels_own_decisions(P, B, k, seed):
         elif rel_err(g, r) >= 1e-4:
             bad.append((n, float(rel_err(g, r))))
     assert not bad, bad
+
+
+def test_config4_trainer_step_at_full_size():
+    """One fused Trainer.step at the training configuration (B = 256 per GPU, P = 750) against the float32 oracle
+    step from the same state: loss, log-probabilities, running statistics of all ten BatchNorm layers and the batch
+    counters.  (Gradients at this size are compared in test_gradients_with_the_kernels_own_decisions[750-256-...]:
+    with 10^8 max / ReLU decisions per step a plain float32 comparison of gradients tests luck.)  Post-Adam
+    parameters are compared where the oracle's gradient is clear of zero AND the two float32 gradients agree in
+    sign and to 1 %: there Adam's first update is lr * g / (|g| + eps), the same number for both."""
+    P, k, seed, B, gain = 750, 2, 12, 256, 1.3
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
+    target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) * k).astype(np.int64))
+    sd = synth.torch_state_dict(seed, k, 1.0, gain)
+    oracle = po.build_cls(P, k, sd, eval_mode=False)
+    opt = torch.optim.Adam(oracle.parameters(), lr=0.005)
+    out, _ = oracle(x)
+    loss_ref = F.nll_loss(out, target)
+    loss_ref.backward()
+    g_ref = {n: p.grad.clone() for n, p in oracle.named_parameters()}
+    opt.step()
+    m = hip_train_model(P, k, seed, gain)
+    tr = Trainer(m, lr=0.005)
+    loss, logp = tr.step(x.cuda(), target.cuda())
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    np.testing.assert_allclose(logp.cpu().numpy(), out.detach().numpy(), atol=1e-4)
+    ref_sd, got_sd = oracle.state_dict(), m.state_dict()
+    for n in ref_sd:
+        if n.endswith(("running_mean", "running_var")):
+            np.testing.assert_allclose(got_sd[n].cpu().numpy(), ref_sd[n].numpy(), rtol=2e-4, atol=2e-5, err_msg=n)
+        elif n.endswith("num_batches_tracked"):
+            assert int(got_sd[n]) == int(ref_sd[n]) == 1
+    off, compared = 0, 0
+    for n, p in m.named_parameters():
+        g = tr.flat_g[off:off + p.numel()].cpu().view_as(p)
+        off += p.numel()
+        r = g_ref[n]
+        clear = (r.abs() > 1e-4) & ((g - r).abs() <= 0.01 * r.abs())
+        if clear.any():
+            d = (got_sd[n].cpu() - ref_sd[n]).abs()[clear]
+            assert float(d.max()) < 1e-4, (n, float(d.max()))
+            compared += int(clear.sum())
+    assert compared > 100_000
