@@ -10,9 +10,8 @@ What is kept from the reference, because results depend on it:
   * scalars 'train_loss' (every log_interval batches, at batch_idx + epoch*len(loader)), 'train_acc', 'test_acc',
     'test_loss' (per epoch) (main_1v.py:295-297, 344-346);
   * every save_interval epochs the WHOLE module is pickled (main_1v.py:347-351) under the reference's class path,
-    so `compat.load_checkpoint` and the reference's own torch.load both read it back.  The container is torch's
-    zip format, not the pre-1.6 one the reference asks for: torch's restricted unpickler cannot read whole
-    modules from the old container (compat.load_checkpoint.__doc__).
+    in torch's pre-1.6 container like the reference (`_use_new_zipfile_serialization=False`), so
+    `compat.load_checkpoint` and the reference's own torch.load both read it back.
 
 What is not reproduced: PointGraspOneViewDataset (it needs dex-net, autolab_core and python-pcl, model/dataset.py:5-29).
 `main` trains on `.npz` shards holding `points[n,3,P]` float32 and `labels[n]` int64 (what that dataset's
@@ -170,11 +169,12 @@ def test_epoch(model, loader, device="cuda"):
     return acc, test_loss, res
 
 
-def save_model(model, path):
-    """Whole-module pickle under the reference's class path (main_1v.py:350), zip container."""
+def save_model(model, path, old_container=True):
+    """Whole-module pickle under the reference's class path in the container the reference writes
+    (torch.save(model, path, _use_new_zipfile_serialization=False), main_1v.py:350)."""
     from .compat import save_checkpoint
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    save_checkpoint(model, path)
+    save_checkpoint(model, path, old_container=old_container)
 
 
 def _load_arrays(path, tag, num_points):

@@ -2,6 +2,7 @@
 from the CPU restatement with the class path the reference's files carry (`model.pointnet.*`,
 main_1v.py:350); the reference's own checkpoints are not available to this build."""
 import collections
+import os
 import sys
 import types
 
@@ -47,7 +48,8 @@ def test_whole_module_pickle_maps_onto_native_classes(legacy_pickle, data_parall
     assert type(m) is pn.PointNetCls and type(m.feat) is pn.PointNetfeat and type(m.feat.stn) is pn.STN3d
     assert m.num_points == 750 and not m.training and m.fc3.out_features == 2
     got, want = m.state_dict(), ref.state_dict()
-    assert list(got.keys()) == list(want.keys())
+    assert sorted(got.keys()) == sorted(want.keys())
+    assert list(got.keys()) == list(pn.PointNetCls(750, 3, 2).state_dict().keys())      # rebuilt: native key order
     for k in want:
         assert torch.equal(got[k], want[k]), k
     assert "model" not in sys.modules and "model.pointnet" not in sys.modules
@@ -106,19 +108,108 @@ def test_save_checkpoint_round_trip_and_class_path(tmp_path):
         assert torch.equal(a, b), k
 
 
-def test_old_container_is_refused_with_an_explanation(tmp_path):
-    """main_1v.py:350 writes torch's pre-1.6 non-zip container; torch's restricted unpickler cannot read whole
-    modules from it and the loader does not fall back to unrestricted unpickling."""
-    import warnings
+def test_old_container_round_trip(tmp_path):
+    """main_1v.py:350 writes torch's pre-1.6 non-zip container (`_use_new_zipfile_serialization=False`): whole
+    modules, bare or wrapped in DataParallel, and state_dicts load from it."""
     m = pn.PointNetCls(32, 3, 2)
-    path = str(tmp_path / "old.model")
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        compat.save_checkpoint(m, path, old_container=True)
-    with pytest.raises(ValueError, match="non-zip container"):
-        compat.load_checkpoint(path, device="cpu")
-    # a state_dict in the old container holds tensors only and loads
+    m.load_state_dict(synth.torch_state_dict(9, 2, 1.0))
+    for wrap in (False, True):
+        path = str(tmp_path / f"old{int(wrap)}.model")
+        compat.save_checkpoint(torch.nn.DataParallel(m) if wrap else m, path, old_container=True)
+        import zipfile
+        assert not zipfile.is_zipfile(path) and compat._is_legacy_container(path)
+        back = compat.load_checkpoint(path, device="cpu")
+        assert type(back) is pn.PointNetCls and type(back.feat.stn) is pn.STN3d and back.num_points == 32
+        assert list(back.state_dict()) == list(m.state_dict())
+        assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), back.state_dict().values()))
+        with pytest.raises(ValueError, match="num_points=32"):
+            compat.load_checkpoint(path, num_points=750, device="cpu")
+    assert type(m) is pn.PointNetCls and "model" not in sys.modules
     sd_path = str(tmp_path / "old_sd.pth")
     torch.save(m.state_dict(), sd_path, _use_new_zipfile_serialization=False)
     back = compat.load_checkpoint(sd_path, num_points=32, device="cpu")
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), back.state_dict().values()))
+
+
+class _Hostile:
+    def __reduce__(self):
+        import os
+        return (os.getcwd, ())
+
+
+def test_legacy_reader_resolves_nothing_outside_its_table(tmp_path):
+    """The pre-1.6 container is read by an own restricted unpickler: a file that names any other callable or class
+    is refused before anything is called, and a damaged file is reported."""
+    import pickle
+    import warnings
+    bad = str(tmp_path / "hostile.model")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.save({"weights": torch.zeros(3), "x": _Hostile()}, bad, _use_new_zipfile_serialization=False)
+    assert compat._is_legacy_container(bad)
+    with pytest.raises(pickle.UnpicklingError, match="getcwd"):
+        compat.load_checkpoint(bad, device="cpu")
+    other = str(tmp_path / "other_module.model")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.save(torch.nn.Sequential(torch.nn.Tanh()), other, _use_new_zipfile_serialization=False)
+    with pytest.raises(pickle.UnpicklingError, match="Sequential|Tanh"):
+        compat.load_checkpoint(other, device="cpu")
+    m = pn.PointNetCls(16, 3, 2)
+    good = str(tmp_path / "good.model")
+    compat.save_checkpoint(m, good, old_container=True)
+    blob = open(good, "rb").read()
+    cut = str(tmp_path / "cut.model")
+    open(cut, "wb").write(blob[:len(blob) - 1000])
+    with pytest.raises((ValueError, EOFError, pickle.UnpicklingError)):
+        compat.load_checkpoint(cut, device="cpu")
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "model")),
+                    reason="needs the reference checkout (build container only)")
+def test_checkpoints_written_by_the_reference_classes_load_unchanged(tmp_path):
+    """What main_1v.py:350 does, with the reference's own class imported from its checkout: torch.save(model, path,
+    _use_new_zipfile_serialization=False), bare and DataParallel-wrapped (main_test.py:69 unwraps), plus the zip
+    container.  All three load, and the reference's torch.load reads what save_checkpoint writes."""
+    import subprocess
+    import textwrap
+    # the reference classes are imported in a child process so that `model.pointnet` never enters this one
+    script = textwrap.dedent(f"""
+        import sys, warnings
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, {REFERENCE!r}); sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        import torch
+        from model.pointnet import PointNetCls
+        from pointnetgpd_amd import synth
+        m = PointNetCls(750, 3, 2)
+        m.load_state_dict(synth.torch_state_dict(5, 2, 0.02))
+        warnings.simplefilter("ignore")
+        torch.save(m, sys.argv[1] + "/ref_old.model", _use_new_zipfile_serialization=False)
+        torch.save(torch.nn.DataParallel(m), sys.argv[1] + "/ref_old_dp.model", _use_new_zipfile_serialization=False)
+        torch.save(m, sys.argv[1] + "/ref_zip.model")
+        if len(sys.argv) > 2:                      # second call: read back what save_checkpoint wrote
+            back = torch.load(sys.argv[2], map_location="cpu", weights_only=False)
+            assert type(back).__module__ == "model.pointnet" and type(back) is PointNetCls
+            x = torch.from_numpy(synth.candidate_points(5, 3, 750, "gripper"))
+            a, _ = back.eval()(x); b, _ = m.eval()(x)
+            assert torch.equal(a, b)
+            print("reference-read-ok")
+    """)
+    subprocess.run([sys.executable, "-c", script, str(tmp_path)], check=True)
+    want = synth.torch_state_dict(5, 2, 0.02)
+    for name in ("ref_old.model", "ref_old_dp.model", "ref_zip.model"):
+        back = compat.load_checkpoint(str(tmp_path / name), device="cpu")
+        assert type(back) is pn.PointNetCls and back.num_points == 750 and not back.training
+        got = back.state_dict()
+        assert sorted(got) == sorted(want) and list(got) == list(pn.PointNetCls(750, 3, 2).state_dict())
+        for k in want:
+            assert torch.equal(got[k], want[k].to(got[k].dtype).reshape(got[k].shape)), k
+    ours = str(tmp_path / "ours_old.model")
+    m = pn.PointNetCls(750, 3, 2)
+    m.load_state_dict(want)
+    compat.save_checkpoint(m, ours, old_container=True)
+    out = subprocess.run([sys.executable, "-c", script, str(tmp_path), ours], check=True, capture_output=True, text=True)
+    assert "reference-read-ok" in out.stdout
