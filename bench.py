@@ -186,6 +186,13 @@ def online_workload(args, dev, rank, n_gpus, dist):
     total_idx = int(counts.sum().item())
     # algorithmic bytes of the stage: scene once, grasps, counts, and the network input it writes
     crop_bytes = S * 12 + G * 15 * 8 + G * 4 + G * R * P * 3 * 4
+    # HBM bytes of the stage per frame from the committed PMC passes, when they ran this configuration
+    crop_traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r2_crop_stage_traffic.json")
+    if os.path.exists(tpath):
+        t = json.load(open(tpath))
+        if t["config"] == {"S": S, "G": G, "R": R, "P": P}:
+            crop_traffic = t["hbm_bytes_per_frame"]
     if rank == 0:
         crop_gbps = crop_bytes / (crop_ms * 1e-3) / 1e9
         line = {
@@ -197,11 +204,12 @@ def online_workload(args, dev, rank, n_gpus, dist):
                        "crop_ms": round(crop_ms, 3), "score_ms": round(score_ms, 3), "pair_tests_per_s": round(S * G / (crop_ms * 1e-3), 1),
                        "crop_algorithmic_GBps": round(crop_bytes / (crop_ms * 1e-3) / 1e9, 2),
                        "mean_points_per_grasp": round(total_idx / G, 1), "good_grasps": int(out.order.numel())},
-            # the crop + subsample stage against the HBM roofline (its traversal is latency-bound: the algorithmic
-            # bytes are small); the stage that dominates the frame is the scoring, whose kernel the score workload reports
+            # the crop + subsample stage against the HBM roofline (its main kernel is bound by vector-instruction
+            # issue, profiles/r2_crop_stage.md); the stage that dominates the frame is the scoring, whose kernel the
+            # score workload reports
             "roofline": {"bound": "hbm", "kernel": "crop + subsample (grid build and k_cull_gather)",
                          "achieved": round(crop_gbps, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(crop_gbps / 8000.0, 5), "traffic": None, "stage_ms": round(crop_ms, 3),
+                         "frac": round(crop_gbps / 8000.0, 5), "traffic": crop_traffic, "stage_ms": round(crop_ms, 3),
                          "bytes_per_frame": crop_bytes},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -193,28 +193,34 @@ def _mix32(x):
         return x ^ (x >> np.uint32(15))
 
 
+def _feistel_f(half, key):
+    with np.errstate(over="ignore"):
+        return ((np.asarray(half, dtype=np.uint32) ^ np.uint32(key)) * np.uint32(0x9E3779B1)) >> np.uint32(16)
+
+
 def draw_selection(seed: int, g: int, r: int, n: int, P: int, replace_when_equal: bool = False) -> np.ndarray:
-    """The P positions the device draws for (grasp g, repeat r) when the grasp holds n points.
+    """The P positions the device draws for (grasp g, repeat r) when the grasp holds n points (csrc/crop_select.h).
+    n >= P: the first P numbers below n of pi(0), pi(1), ... for a keyed 4-round Feistel permutation pi of
+    [0, 2^ceil(log2 n)); n < P: independent uniform draws.
     replace_when_equal: the dataset's rule (n == P drawn with replacement, model/dataset.py:1104)."""
     with np.errstate(over="ignore"):
         inner = _mix64((np.uint64(g) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(r)) & _M)
         key = _mix64(np.uint64(seed & (2 ** 64 - 1)) ^ inner)
-        if n < P + int(replace_when_equal):
-            i = np.arange(P, dtype=np.uint64)
-            u = _mix64((key + i) & _M) >> np.uint64(32)
-            return ((u * np.uint64(n)) >> np.uint64(32)).astype(np.int32)
-        hb = 1
-        while (1 << (2 * hb)) < n:
-            hb += 1
-        m = np.uint32((1 << hb) - 1)
         rk = [np.uint32(int(_mix64((key + (np.uint64(t + 1) << np.uint64(32))) & _M)) >> 32) for t in range(4)]
-        x = np.arange(P, dtype=np.uint32)
-        todo = np.ones(P, dtype=bool)
-        while todo.any():
-            L, Rh = x[todo] >> np.uint32(hb), x[todo] & m
-            for t in range(4):
-                F = _mix32(Rh ^ rk[t]) & m
-                L, Rh = Rh, L ^ F
-            x[todo] = (L << np.uint32(hb)) | Rh
-            todo = x >= np.uint32(n)
-        return x.astype(np.int32)
+        if n < P + int(replace_when_equal):
+            i = np.arange(P, dtype=np.uint32)
+            u = _mix32(i * np.uint32(0x9E3779B9) + rk[0]).astype(np.uint64)
+            return ((u * np.uint64(n)) >> np.uint64(32)).astype(np.int32)
+        b = 2
+        while (1 << b) < n:
+            b += 1
+        a = b >> 1
+        a_mask, c_mask = np.uint32((1 << a) - 1), np.uint32((1 << (b - a)) - 1)
+        t = np.arange(1 << b, dtype=np.uint32)
+        hi, lo = t >> np.uint32(a), t & a_mask
+        hi = hi ^ (_feistel_f(lo, rk[0]) & c_mask)
+        lo = lo ^ (_feistel_f(hi, rk[1]) & a_mask)
+        hi = hi ^ (_feistel_f(lo, rk[2]) & c_mask)
+        lo = lo ^ (_feistel_f(hi, rk[3]) & a_mask)
+        x = (hi << np.uint32(a)) | lo
+        return x[x < np.uint32(n)][:P].astype(np.int32)

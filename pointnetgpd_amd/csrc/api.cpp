@@ -390,9 +390,10 @@ int pngpd_forward_infer_timed(const pngpd_model* m, const float* x_dev, int layo
     return rc;
 }
 
-// crop workspace: [G,12] f64 frames | the scene's spatial grid | only in the all-pairs test mode a [G, Wp] u64
-// mask.  Every region is rounded up to 256 B.
+// crop workspace: [G,12] f64 frames | [G] i32 spatial order of the grasps | the scene's spatial grid | only in the
+// all-pairs test mode a [G, Wp] u64 mask.  Every region is rounded up to 256 B.
 static size_t crop_frames_bytes(int G) { return ((size_t)G * 12 * sizeof(double) + 255) & ~(size_t)255; }
+static size_t crop_perm_bytes(int G) { return ((size_t)G * sizeof(int) + 255) & ~(size_t)255; }
 
 static size_t crop_mask_bytes(int S, int G) {
     if (!pngpd::crop_brute_mode()) return 0;
@@ -402,11 +403,13 @@ static size_t crop_mask_bytes(int S, int G) {
 namespace {
 struct CropWs {
     double* frames;
+    int* perm;
     void* grid;
     unsigned long long* mask;
     CropWs(const void* base, int S, int G) {
         char* p = (char*)base;
         frames = (double*)p;              p += crop_frames_bytes(G);
+        perm = (int*)p;                   p += crop_perm_bytes(G);
         grid = p;                         p += pngpd::crop_grid_bytes(S);
         mask = pngpd::crop_brute_mode() ? (unsigned long long*)p : nullptr;
     }
@@ -415,7 +418,7 @@ struct CropWs {
 
 size_t pngpd_crop_workspace_bytes(int S, int G) {
     if (S < 1 || G < 1) return 0;
-    return crop_frames_bytes(G) + pngpd::crop_grid_bytes(S) + crop_mask_bytes(S, G);
+    return crop_frames_bytes(G) + crop_perm_bytes(G) + pngpd::crop_grid_bytes(S) + crop_mask_bytes(S, G);
 }
 
 static int crop_ws_check(int S, int G, const void* ws, size_t bytes) {
@@ -511,7 +514,7 @@ int pngpd_crop_subsample(const float* scene_dev, int S, const double* grasps_dev
     HIP_TRY(pngpd::launch_crop_frames(grasps_dev, w.frames, G, (hipStream_t)stream));
     HIP_TRY(pngpd::launch_crop_gather_fused(scene_dev, S, w.frames, G, L, w.grid, repeat, P, min_points, seed,
                                             first_grasp_id, pts_out_dev, valid_dev, cnt_dev, overflow_dev,
-                                            (hipStream_t)stream));
+                                            w.perm, (hipStream_t)stream));
     return PNGPD_OK;
 }
 

@@ -276,36 +276,44 @@ __global__ __launch_bounds__(256) void crop_gather_kernel(const float* __restric
         }
         __syncthreads();
     }
-    for (int r = 0; r < R; ++r) {
-        const size_t row = (size_t)g * R + r;
+    auto place = [&](size_t row, int i, int j) {       // draw i of candidate `row` is point j of the grasp
         float* out = pts_out + row * P * 3;
+        if (sel_out != nullptr) sel_out[row * P + i] = j;
+        float x, y, z;
+        if (in_lds) {
+            x = s_pts[3 * j + 0];
+            y = s_pts[3 * j + 1];
+            z = s_pts[3 * j + 2];
+        } else {
+            const float* p = scene + (size_t)idx[base + j] * 3;
+            const PointD q = to_gripper(f, (double)p[0], (double)p[1], (double)p[2]);
+            x = (float)q.x;
+            y = (float)q.y;
+            z = (float)q.z;
+        }
+        if (channels_first) {        // [3,P]: grasp_pc[...].T of the dataset (model/dataset.py:1106)
+            out[i] = x;
+            out[P + i] = y;
+            out[2 * P + i] = z;
+        } else {
+            out[3 * i + 0] = x;
+            out[3 * i + 1] = y;
+            out[3 * i + 2] = z;
+        }
+    };
+    if (sel != nullptr) {                               // positions given by the caller
+        for (int r = 0; r < R; ++r) {
+            const size_t row = (size_t)g * R + r;
+            for (int i = tid; i < P; i += 256) place(row, i, sel[row * P + i]);
+        }
+        return;
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < R; r += 4) {                 // a wave draws whole repeats (wave_draws)
         Selector pick;
         pick.init(seed, first_grasp_id + g, r, n, P, replace_when_equal);
-        for (int i = tid; i < P; i += 256) {
-            const int j = sel != nullptr ? sel[row * P + i] : pick.draw(i);
-            if (sel_out != nullptr) sel_out[row * P + i] = j;
-            float x, y, z;
-            if (in_lds) {
-                x = s_pts[3 * j + 0];
-                y = s_pts[3 * j + 1];
-                z = s_pts[3 * j + 2];
-            } else {
-                const float* p = scene + (size_t)idx[base + j] * 3;
-                const PointD q = to_gripper(f, (double)p[0], (double)p[1], (double)p[2]);
-                x = (float)q.x;
-                y = (float)q.y;
-                z = (float)q.z;
-            }
-            if (channels_first) {        // [3,P]: grasp_pc[...].T of the dataset (model/dataset.py:1106)
-                out[i] = x;
-                out[P + i] = y;
-                out[2 * P + i] = z;
-            } else {
-                out[3 * i + 0] = x;
-                out[3 * i + 1] = y;
-                out[3 * i + 2] = z;
-            }
-        }
+        const size_t row = (size_t)g * R + r;
+        wave_draws(pick, P, lane, [&](int i, int j) { place(row, i, j); });
     }
 }
 

@@ -9,12 +9,13 @@
 // sizes) in LDS, sorts them there - np.where order is ascending - and writes the index and point lists.
 //
 //   bounds  : min/max of the scene                      -> grid origin, cell size, dimensions
-//   count   : cell of every point + histogram (atomics)
+//   count   : cell of every point + histogram; the atomic's return value is the point's rank inside its cell
 //   scan    : exclusive prefix over the (at most 64^3) cells
-//   scatter : points regrouped by cell as float4 {x, y, z, original index}
+//   scatter : points regrouped by cell as float4 {x, y, z, original index} at start[cell] + rank (no atomics)
 //   cull    : twice - count (one wave per grasp), emit (one workgroup per grasp); x-runs of cells are contiguous
 //             in the regrouped array
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "crop_math.h"
 #include "crop_select.h"
@@ -25,9 +26,11 @@ namespace pngpd {
 constexpr int BOUNDS_BLOCK_PTS = 4096;
 
 __global__ __launch_bounds__(256) void k_bounds_partial(const float* __restrict__ scene, int S,
-                                                        float* __restrict__ part) {
+                                                        float* __restrict__ part, int* __restrict__ hist) {
     __shared__ float smin[3][256], smax[3][256];
     const int tid = threadIdx.x;
+    // the cell histogram of the pass after next starts from zero: cleared here rather than by a fill of its own
+    for (int i = blockIdx.x * 256 + tid; i <= GRID_CELLS; i += gridDim.x * 256) hist[i] = 0;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     const int s0 = blockIdx.x * BOUNDS_BLOCK_PTS, s1 = min(S, s0 + BOUNDS_BLOCK_PTS);
     for (int s = s0 + tid; s < s1; s += 256)
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void k_bounds_partial(const float* __restrict_
 
 // one block: reduce the partial bounds, derive the grid, clear the histogram tail marker
 __global__ __launch_bounds__(256) void k_grid_setup(const float* __restrict__ part, int nblk, double cell_req,
-                                                    GridParams* __restrict__ gp) {
+                                                    GridParams* __restrict__ gp, int* __restrict__ clear_flag) {
     __shared__ float smin[3][256], smax[3][256];
     const int tid = threadIdx.x;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(256) void k_grid_setup(const float* __restrict__ pa
         __syncthreads();
     }
     if (tid == 0) {
+        if (clear_flag != nullptr) *clear_flag = 0;
         double ext = 0.0;
         for (int c = 0; c < 3; ++c) ext = fmax(ext, (double)smax[c][0] - (double)smin[c][0]);
         double cell = fmax(cell_req, ext / (GRID_MAX_DIM - 1));
@@ -93,22 +97,95 @@ __device__ __forceinline__ int cell_coord(double v, double origin, double inv_ce
 }
 
 __global__ void k_cell_count(const float* __restrict__ scene, int S, const GridParams* __restrict__ gp,
-                             int* __restrict__ cell_of, int* __restrict__ hist) {
+                             int2* __restrict__ cell_rank, int* __restrict__ hist) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     const int ix = cell_coord((double)scene[(size_t)s * 3 + 0], gp->origin[0], gp->inv_cell, gp->dim[0]);
     const int iy = cell_coord((double)scene[(size_t)s * 3 + 1], gp->origin[1], gp->inv_cell, gp->dim[1]);
     const int iz = cell_coord((double)scene[(size_t)s * 3 + 2], gp->origin[2], gp->inv_cell, gp->dim[2]);
     const int cell = ix + gp->dim[0] * (iy + gp->dim[1] * iz);
-    cell_of[s] = cell;
-    atomicAdd(&hist[cell], 1);
+    // one device-scope atomic per point is what this pass costs (~24 G/s); taking the rank from it here spares the
+    // regrouping pass a second one
+    cell_rank[s] = make_int2(cell, atomicAdd(&hist[cell], 1));
+}
+
+// Spatial order of the grasps for the one-pass kernel.  A grasp streams the ~4 k points of the cells around its
+// box out of the cell-sorted array (16 MB at a million points: more than the 4 MiB L2 of an XCD), so which grasps
+// run next to each other decides whether those lines come from the L2 or from beyond it.  perm[] lists the grasps
+// by the Morton code of the coarse cell (16 per axis) that holds their box centre - a counting sort by one
+// workgroup (the second workgroup of the k_scan_cells launch: both need only the grid's parameters, so the order
+// costs no launch and no time of its own); the order inside a cell is whatever the atomics give, which changes
+// scheduling only, never results.
+constexpr int ORDER_BINS = 4096;
+
+__device__ __forceinline__ unsigned part_bits4(unsigned v) {          // abcd -> 00a00b00c00d
+    v = (v | (v << 4)) & 0x0C3u;
+    v = (v | (v << 2)) & 0x249u;
+    return v;
+}
+
+__device__ __forceinline__ int grasp_bin(const double* __restrict__ f, const CropLimits& L,
+                                         const GridParams* __restrict__ gp) {
+    const double mx = 0.5 * (L.xlo + L.xhi), my = 0.5 * (L.ylo + L.yhi), mz = 0.5 * (L.zlo + L.zhi);
+    unsigned code = 0;
+    for (int c = 0; c < 3; ++c) {
+        const double w = f[c] + mx * f[3 + c] + my * f[6 + c] + mz * f[9 + c];      // box centre (unit rows assumed)
+        double t = (w - gp->origin[c]) * gp->inv_cell * 16.0 / (double)gp->dim[c];
+        t = t >= 0.0 ? t : 0.0;                                                     // NaN lands in bin 0
+        const unsigned q = t < 15.0 ? (unsigned)t : 15u;
+        code |= part_bits4(q) << c;
+    }
+    return (int)code;
+}
+
+__device__ __forceinline__ void grasp_order(const double* __restrict__ frames, int G, const CropLimits& L,
+                                            const GridParams* __restrict__ gp, int* __restrict__ perm, int* s_bin,
+                                            int* s_wave) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < ORDER_BINS; i += 1024) s_bin[i] = 0;
+    __syncthreads();
+    for (int g = tid; g < G; g += 1024) atomicAdd(&s_bin[grasp_bin(frames + (size_t)g * 12, L, gp)], 1);
+    __syncthreads();
+    const int c0 = s_bin[4 * tid], c1 = s_bin[4 * tid + 1], c2 = s_bin[4 * tid + 2], c3 = s_bin[4 * tid + 3];
+    const int sum = c0 + c1 + c2 + c3;
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += s_wave[w];
+    s_bin[4 * tid] = run;
+    s_bin[4 * tid + 1] = run + c0;
+    s_bin[4 * tid + 2] = run + c0 + c1;
+    s_bin[4 * tid + 3] = run + c0 + c1 + c2;
+    __syncthreads();
+    for (int g = tid; g < G; g += 1024)
+        perm[atomicAdd(&s_bin[grasp_bin(frames + (size_t)g * 12, L, gp)], 1)] = g;
+}
+
+// Position in perm[] that workgroup `b` of `n` takes: workgroups are handed to the 8 XCDs in turn, so the
+// workgroups b, b + 8, b + 16, ... share an L2; they get one contiguous eighth of the spatial order.
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
 // exclusive scan of hist over the cells in use into start[0..ncells]; cursor = copy.  One block of 1024 threads
 // walks the cells in chunks of 4096 (one int4 per thread: coalesced) and carries the running total.
 __global__ __launch_bounds__(1024) void k_scan_cells(const GridParams* __restrict__ gp, const int* __restrict__ hist,
-                                                     int* __restrict__ start, int* __restrict__ cursor) {
+                                                     int* __restrict__ start, int* __restrict__ cursor,
+                                                     const double* __restrict__ frames, int G, CropLimits L,
+                                                     int* __restrict__ perm) {
     __shared__ int s_wave[16];
+    if (blockIdx.x == 1) {                              // launched only when an order is wanted
+        __shared__ int s_bin[ORDER_BINS];
+        grasp_order(frames, G, L, gp, perm, s_bin, s_wave);
+        return;
+    }
     const int ncells = gp->dim[0] * gp->dim[1] * gp->dim[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int carry = 0;
@@ -152,11 +229,12 @@ __global__ __launch_bounds__(1024) void k_scan_cells(const GridParams* __restric
     if (tid == 0) start[ncells] = carry;
 }
 
-__global__ void k_scatter(const float* __restrict__ scene, int S, const int* __restrict__ cell_of,
-                          int* __restrict__ cursor, float4* __restrict__ sorted) {
+__global__ void k_scatter(const float* __restrict__ scene, int S, const int2* __restrict__ cell_rank,
+                          const int* __restrict__ start, float4* __restrict__ sorted) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
-    const int pos = atomicAdd(&cursor[cell_of[s]], 1);
+    const int2 cr = cell_rank[s];
+    const int pos = start[cr.x] + cr.y;
     sorted[pos] = make_float4(scene[(size_t)s * 3], scene[(size_t)s * 3 + 1], scene[(size_t)s * 3 + 2],
                               __int_as_float(s));
 }
@@ -232,6 +310,30 @@ __device__ __forceinline__ bool row_range(const double* __restrict__ f, const Cr
     if (kept == 0ull) return false;
     const int first = __ffsll((long long)kept) - 1, last = 63 - __clzll((long long)kept);
     const int cb = gp->dim[0] * (iy + gp->dim[1] * iz) + gc.c0[0];
+    p0 = start[cb + first];
+    p1 = start[cb + last + 1];
+    return p0 < p1;
+}
+
+// The same range found by ONE thread walking the row's cells (at most GRID_MAX_DIM, a handful for a gripper-sized
+// box): every thread of a workgroup can then take a row of its own.
+__device__ __forceinline__ bool row_range_serial(const double* __restrict__ f, const CropLimits& L, const GraspCells& gc,
+                                                 const GridParams* __restrict__ gp, const int* __restrict__ start,
+                                                 int iy, int iz, int& p0, int& p1) {
+    const double cell = 1.0 / gp->inv_cell;
+    const double cy = gp->origin[1] + (iy + 0.5) * cell, cz = gp->origin[2] + (iz + 0.5) * cell;
+    int first = -1, last = -1;
+    for (int ix = gc.c0[0]; ix <= gc.c1[0]; ++ix) {
+        const PointD q = to_gripper(f, gp->origin[0] + (ix + 0.5) * cell, cy, cz);
+        const bool keep = (q.x > L.xlo - gc.slack[0]) & (q.x < L.xhi + gc.slack[0]) & (q.y > L.ylo - gc.slack[1]) &
+                          (q.y < L.yhi + gc.slack[1]) & (q.z > L.zlo - gc.slack[2]) & (q.z < L.zhi + gc.slack[2]);
+        if (keep) {
+            if (first < 0) first = ix;
+            last = ix;
+        }
+    }
+    if (first < 0) return false;
+    const int cb = gp->dim[0] * (iy + gp->dim[1] * iz);
     p0 = start[cb + first];
     p1 = start[cb + last + 1];
     return p0 < p1;
@@ -503,7 +605,8 @@ __global__ __launch_bounds__(256) void k_cull_gather(const float* __restrict__ s
                                                      const float4* __restrict__ sorted, int R, int P, int min_points,
                                                      unsigned long long seed, int first_grasp_id,
                                                      float* __restrict__ pts_out, unsigned char* __restrict__ valid,
-                                                     int* __restrict__ cnt, int* __restrict__ overflow) {
+                                                     int* __restrict__ cnt, int* __restrict__ overflow,
+                                                     const int* __restrict__ perm) {
     // one 18 KiB buffer: first the hit list (FUSED_CAP indices as found, then as many sorted), later the
     // float32 points - the sorted indices pass through registers in between.  LDS per workgroup decides how many
     // grasps a CU traverses at once, and the traversal is latency-bound.
@@ -513,32 +616,56 @@ __global__ __launch_bounds__(256) void k_cull_gather(const float* __restrict__ s
     float* s_pts = (float*)s_buf;
     __shared__ int s_fill;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x;
+    const int g = perm != nullptr ? perm[xcd_contiguous(blockIdx.x, G)] : blockIdx.x;
     const double* f = frames + (size_t)g * 12;
-    const GraspCells gc = grasp_cells(f, L, gp);
+    // the cell bounds are the same for the whole workgroup: one wave works them out (a few hundred vector
+    // instructions that the other three would only repeat)
+    __shared__ GraspCells s_gc;
+    if (wave == 0) {
+        const GraspCells mine = grasp_cells(f, L, gp);
+        if (lane == 0) {
+            s_gc = mine;
+            s_fill = 0;
+        }
+    }
+    __syncthreads();
+    const GraspCells gc = s_gc;
     const int ny = gc.c1[1] - gc.c0[1] + 1, nrows = ny * (gc.c1[2] - gc.c0[2] + 1);
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (tid == 0) s_fill = 0;
-    __syncthreads();
-    for (int row = wave; row < nrows; row += 4) {
-        const int iy = gc.c0[1] + row % ny, iz = gc.c0[2] + row / ny;
-        int p0, p1;
-        if (!row_range(f, L, gc, gp, start, iy, iz, lane, p0, p1)) continue;
-        for (int p = p0; p < p1; p += 64) {           // wave-uniform trip count: ballots stay whole
-            bool hit = false;
-            int s = 0;
-            if (p + lane < p1) {
-                const float4 v = sorted[p + lane];
-                hit = in_box(to_gripper(f, (double)v.x, (double)v.y, (double)v.z), L);
-                s = __float_as_int(v.w);
+    // Rows of cells in tiles of 256: every thread finds the point range of one row (the kernel is bound by its
+    // vector instructions, and a wave per row spends 64 lanes on a handful of cells), then the waves share the rows.
+    int* row_p0 = s_small;
+    int* row_p1 = s_small + 256;
+    for (int row0 = 0; row0 < nrows; row0 += 256) {
+        __syncthreads();                               // s_fill is set; the previous tile's table has been read
+        {
+            const int row = row0 + tid;
+            int p0 = 0, p1 = 0;
+            if (row < nrows && !row_range_serial(f, L, gc, gp, start, gc.c0[1] + row % ny, gc.c0[2] + row / ny, p0, p1))
+                p0 = p1 = 0;
+            row_p0[tid] = p0;
+            row_p1[tid] = p1;
+        }
+        __syncthreads();
+        const int nt = min(256, nrows - row0);
+        for (int row = wave; row < nt; row += 4) {
+            const int p0 = row_p0[row], p1 = row_p1[row];
+            for (int p = p0; p < p1; p += 64) {        // wave-uniform trip count: ballots stay whole
+                bool hit = false;
+                int s = 0;
+                if (p + lane < p1) {
+                    const float4 v = sorted[p + lane];
+                    hit = in_box(to_gripper(f, (double)v.x, (double)v.y, (double)v.z), L);
+                    s = __float_as_int(v.w);
+                }
+                const unsigned long long bal = __ballot(hit);
+                if (bal == 0ull) continue;
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&s_fill, __popcll(bal));
+                at = __shfl(at, 0);
+                const int pos = at + (int)__popcll(bal & below);
+                if (hit && pos < FUSED_CAP) list[pos] = s;
             }
-            const unsigned long long bal = __ballot(hit);
-            if (bal == 0ull) continue;
-            int at = 0;
-            if (lane == 0) at = atomicAdd(&s_fill, __popcll(bal));
-            at = __shfl(at, 0);
-            const int pos = at + (int)__popcll(bal & below);
-            if (hit && pos < FUSED_CAP) list[pos] = s;
         }
     }
     __syncthreads();
@@ -572,23 +699,22 @@ __global__ __launch_bounds__(256) void k_cull_gather(const float* __restrict__ s
         }
     }
     __syncthreads();
-    for (int r = 0; r < R; ++r) {
+    for (int r = wave; r < R; r += 4) {                 // a wave draws whole repeats (wave_draws)
         Selector pick;
         pick.init(seed, first_grasp_id + g, r, n, P, 0);
         float* o = out + (size_t)r * P * 3;
-        for (int i = tid; i < P; i += 256) {
-            const int j = pick.draw(i);
+        wave_draws(pick, P, lane, [&](int i, int j) {
             o[3 * i + 0] = s_pts[3 * j + 0];
             o[3 * i + 1] = s_pts[3 * j + 1];
             o[3 * i + 2] = s_pts[3 * j + 2];
-        }
+        });
     }
 }
 
 size_t crop_grid_bytes(int S) {
     auto r = [](size_t n) { return (n + 255) & ~(size_t)255; };
     const size_t nblk = (size_t)(S + BOUNDS_BLOCK_PTS - 1) / BOUNDS_BLOCK_PTS;
-    return r(sizeof(GridParams)) + r(nblk * 6 * sizeof(float)) + r((size_t)S * sizeof(int)) +
+    return r(sizeof(GridParams)) + r(nblk * 6 * sizeof(float)) + r((size_t)S * sizeof(int2)) +
            3 * r(((size_t)GRID_CELLS + 1) * sizeof(int)) + r((size_t)S * sizeof(float4));
 }
 
@@ -596,7 +722,8 @@ namespace {
 struct GridWs {
     GridParams* gp;
     float* part;
-    int *cell_of, *hist, *start, *cursor;
+    int2* cell_rank;
+    int *hist, *start, *cursor;
     float4* sorted;
     GridWs(void* grid_ws, int S) {
         auto r = [](size_t n) { return (n + 255) & ~(size_t)255; };
@@ -604,7 +731,7 @@ struct GridWs {
         char* p = (char*)grid_ws;
         gp = (GridParams*)p;          p += r(sizeof(GridParams));
         part = (float*)p;             p += r((size_t)nblk * 6 * sizeof(float));
-        cell_of = (int*)p;            p += r((size_t)S * sizeof(int));
+        cell_rank = (int2*)p;         p += r((size_t)S * sizeof(int2));
         hist = (int*)p;               p += r(((size_t)GRID_CELLS + 1) * sizeof(int));
         start = (int*)p;              p += r(((size_t)GRID_CELLS + 1) * sizeof(int));
         cursor = (int*)p;             p += r(((size_t)GRID_CELLS + 1) * sizeof(int));
@@ -614,7 +741,10 @@ struct GridWs {
 }  // namespace
 
 // Bins the scene: bounds, cell of every point, prefix over the cells, points regrouped by cell.
-static hipError_t build_grid(const float* scene, int S, const CropLimits& L, const GridWs& w, hipStream_t s) {
+// With `perm`, the spatial order of the G grasps (frames) is produced on the way.
+// `clear_flag` (optional) is set to 0 on the way.
+static hipError_t build_grid(const float* scene, int S, const CropLimits& L, const GridWs& w, hipStream_t s,
+                             const double* frames = nullptr, int G = 0, int* perm = nullptr, int* clear_flag = nullptr) {
     const int nblk = (S + BOUNDS_BLOCK_PTS - 1) / BOUNDS_BLOCK_PTS;
     const double ext_x = L.xhi - L.xlo, ext_y = L.yhi - L.ylo, ext_z = L.zhi - L.zlo;
     // cells of a quarter of the region's longest side (the scene's extent / 63 if that is larger): smaller cells
@@ -622,16 +752,14 @@ static hipError_t build_grid(const float* scene, int S, const CropLimits& L, con
     // G = 10k: count + emit + grid build 0.72 / 0.51 / 0.46 / 0.50 ms for 1/8, 1/5, 1/4, 1/3)
     double cell_req = fmax(ext_x, fmax(ext_y, ext_z)) * 0.25;
     if (!(cell_req > 0.0)) cell_req = 1e-3;
-    hipError_t e = hipMemsetAsync(w.hist, 0, ((size_t)GRID_CELLS + 1) * sizeof(int), s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bounds_partial, dim3(nblk), dim3(256), 0, s, scene, S, w.part);
-    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(256), 0, s, (const float*)w.part, nblk, cell_req, w.gp);
+    hipLaunchKernelGGL(k_bounds_partial, dim3(nblk), dim3(256), 0, s, scene, S, w.part, w.hist);
+    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(256), 0, s, (const float*)w.part, nblk, cell_req, w.gp, clear_flag);
     hipLaunchKernelGGL(k_cell_count, dim3((S + 255) / 256), dim3(256), 0, s, scene, S, (const GridParams*)w.gp,
-                       w.cell_of, w.hist);
-    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, s, (const GridParams*)w.gp, (const int*)w.hist, w.start,
-                       w.cursor);
-    hipLaunchKernelGGL(k_scatter, dim3((S + 255) / 256), dim3(256), 0, s, scene, S, (const int*)w.cell_of, w.cursor,
-                       w.sorted);
+                       w.cell_rank, w.hist);
+    hipLaunchKernelGGL(k_scan_cells, dim3(perm != nullptr ? 2 : 1), dim3(1024), 0, s, (const GridParams*)w.gp,
+                       (const int*)w.hist, w.start, w.cursor, frames, G, L, perm);
+    hipLaunchKernelGGL(k_scatter, dim3((S + 255) / 256), dim3(256), 0, s, scene, S, (const int2*)w.cell_rank,
+                       (const int*)w.start, w.sorted);
     return hipGetLastError();
 }
 
@@ -651,17 +779,17 @@ hipError_t launch_crop_count_grid(const float* scene, int S, const double* frame
 hipError_t launch_crop_gather_fused(const float* scene, int S, const double* frames, int G, const CropLimits& L,
                                     void* grid_ws, int R, int P, int min_points, unsigned long long seed,
                                     int first_grasp_id, float* pts_out, unsigned char* valid, int* cnt, int* overflow,
-                                    hipStream_t s) {
+                                    int* perm, hipStream_t s) {
     if (!scene || !frames || !grid_ws || !pts_out || !valid || !cnt || !overflow || S < 1 || G < 1 || R < 1 || P < 1)
         return hipErrorInvalidValue;
+    static const bool ordered = [] { const char* v = getenv("PNGPD_CROP_ORDER"); return !(v && v[0] == '0'); }();
+    if (!ordered || G < 64) perm = nullptr;            // a handful of grasps: nothing to keep apart
     GridWs w(grid_ws, S);
-    hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int), s);
-    if (e != hipSuccess) return e;
-    e = build_grid(scene, S, L, w, s);
+    hipError_t e = build_grid(scene, S, L, w, s, frames, G, perm, overflow);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_cull_gather, dim3(G), dim3(256), 0, s, scene, frames, G, L, (const GridParams*)w.gp,
                        (const int*)w.start, (const float4*)w.sorted, R, P, min_points, seed, first_grasp_id, pts_out,
-                       valid, cnt, overflow);
+                       valid, cnt, overflow, (const int*)perm);
     return hipGetLastError();
 }
 

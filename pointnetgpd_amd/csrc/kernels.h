@@ -94,7 +94,7 @@ hipError_t launch_crop_emit_grid(const float* scene, int S, const double* frames
 hipError_t launch_crop_gather_fused(const float* scene, int S, const double* frames, int G, const CropLimits& L,
                                     void* grid_ws, int R, int P, int min_points, unsigned long long seed,
                                     int first_grasp_id, float* pts_out, unsigned char* valid, int* cnt, int* overflow,
-                                    hipStream_t s);
+                                    int* perm, hipStream_t s);
 hipError_t launch_crop_frames(const double* grasps, double* frames, int G, hipStream_t s);
 // frames [G,12] of training-data grasp records [G,stride] (centre, axis, width, angle, ...) under a 4x4 transform
 hipError_t launch_dataset_frames(const double* records, int stride, int G, const double* transform16, double hand_depth,
