@@ -267,13 +267,29 @@ def train_workload(args, dev, rank, n_gpus, dist):
             "config": {"workload": f"PointNetCls {k}-class train step, P={P}, batch {B} per GPU, Adam lr 0.005, "
                                    "flat fp32 gradient bucket all-reduced over RCCL",
                        "loss": round(float(loss.item()), 5), "reference_equivalent_tflops": round(flop * args.steps / elapsed / 1e12, 2)},
-            "roofline": {"bound": "mfma", "kernel": "conv3_pool_train (fp32 MFMA)", "achieved": round(conv3_tf, 2),
-                         "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": round(conv3_tf / PEAK_TFLOPS["fp32"], 4),
-                         "traffic": None, "kernel_ms": round(conv3_ms, 4), "flop_per_launch": conv3_flop},
+            "roofline": _train_roofline(conv3_tf, conv3_ms, conv3_flop),
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_train(P, k)
         print(json.dumps(line), flush=True)
+
+
+def _train_roofline(conv3_tf, conv3_ms, conv3_flop):
+    """Roofline entry of the training step's dominant kernel, the fused conv3 product / max / arg-max.  Its default
+    form computes float32-grade products on the bfloat16 matrix pipe: every operand is split into three bfloat16
+    pieces and six piece products are accumulated, so a launch executes 6 x the algorithmic flops on
+    v_mfma_f32_32x32x16_bf16.  `achieved` is algorithmic flops over time, as for every other line; `peak` is what the
+    pipe can deliver of such products, the dense bfloat16 peak / 6.  PNGPD_TRAIN_CONV3=f32 selects the float32
+    matrix instruction instead (peak 157.3)."""
+    if os.environ.get("PNGPD_TRAIN_CONV3", "").startswith("f"):
+        peak, kernel = PEAK_TFLOPS["fp32"], "conv3_pool_train_kernel (v_mfma_f32_32x32x2_f32)"
+    else:
+        peak = round(PEAK_TFLOPS["bf16"] / 6.0, 1)
+        kernel = ("conv3_pool_train_x6_kernel (float32-grade products as 6 bf16 piece products on "
+                  "v_mfma_f32_32x32x16_bf16; peak = dense bf16 peak / 6)")
+    return {"bound": "mfma", "kernel": kernel, "achieved": round(conv3_tf, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(conv3_tf / peak, 4), "traffic": None, "kernel_ms": round(conv3_ms, 4),
+            "flop_per_launch": conv3_flop, "executed_bf16_tflops": round(6.0 * conv3_tf, 1) if peak != PEAK_TFLOPS["fp32"] else None}
 
 
 def voxel_workload(args, dev, rank, n_gpus, dist):

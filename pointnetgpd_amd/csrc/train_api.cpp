@@ -65,6 +65,7 @@ struct TrainWs {
             s->c3.abar_d = a.take<double>(C2);
             s->c3.cov = a.take<double>((size_t)C2 * C2);
             s->c3.w3p = a.take<float>((size_t)C3 * C2);
+            s->c3.w3s = a.take<unsigned short>((size_t)3 * C3 * C2);
             s->c3.sh = a.take<float>(C3);
             s->c3.gmask = a.take<float>((size_t)B * C3);
             s->c3.G = a.take<float>((size_t)C2 * C2);

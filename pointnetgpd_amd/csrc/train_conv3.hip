@@ -16,6 +16,7 @@
 //             dgamma = sum g*yhat_arg, dbeta = sum g.
 // Small reductions run in double, in a fixed order (reproducible).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -200,6 +201,13 @@ __device__ __forceinline__ int w3p_index(int c, int k) {
     return (((nt * 16 + 4 * t + g) * 64) + r + 32 * hh) * 4 + e;
 }
 
+// Index of piece 0 (hi) of W3[c][k] in the split-bfloat16 image: [nt 32][ks 8][piece 3][lane 64][8], the B fragments
+// of v_mfma_f32_32x32x16_bf16 (lane l holds channel 32nt + l%32, k = 16ks + 8(l/32) + j).  Pieces are 512 values apart.
+__device__ __forceinline__ int w3s_index(int c, int k) {
+    const int nt = c >> 5, r = c & 31, ks = k >> 4, hh = (k >> 3) & 1, j = k & 7;
+    return (((nt * 8 + ks) * 3) * 64 + r + 32 * hh) * 8 + j;
+}
+
 // one block of 128 threads per channel
 __global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restrict__ W3, const float* __restrict__ b3,
                                                           const float* __restrict__ gamma,
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restric
                                                           float* __restrict__ mean, float* __restrict__ rstd,
                                                           float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float* __restrict__ w3p,
+                                                          unsigned short* __restrict__ w3s,
                                                           float* __restrict__ sh) {
     __shared__ double s_w[C2], s_q[C2], s_m[C2];
     __shared__ float s_sc;
@@ -242,7 +251,19 @@ __global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restric
         sh[c] = (float)((double)beta[c] - (double)sc * wa);
     }
     __syncthreads();
-    w3p[w3p_index(c, i)] = wf * s_sc;
+    const float wv = wf * s_sc;
+    w3p[w3p_index(c, i)] = wv;
+    if (w3s != nullptr) {
+        // the same weight as three bfloat16 pieces (wv = hi + mid + lo to 2^-27), in 32x32x16 fragment order
+        const __bf16 hi = (__bf16)wv;
+        const float r1 = wv - (float)hi;
+        const __bf16 mid = (__bf16)r1;
+        const __bf16 lo = (__bf16)(r1 - (float)mid);
+        const int base = w3s_index(c, i);
+        w3s[base] = __builtin_bit_cast(unsigned short, hi);
+        w3s[base + 512] = __builtin_bit_cast(unsigned short, mid);
+        w3s[base + 1024] = __builtin_bit_cast(unsigned short, lo);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -334,6 +355,166 @@ __global__ __launch_bounds__(TC_THREADS, 2) void conv3_pool_train_kernel(const f
                         for (int mt = 0; mt < TC_MT; ++mt)
                             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X[mt][t][4 * (q & 3) + e], bw[e], acc[mt], 0,
                                                                           0, 0);
+                }
+                __syncthreads();
+            }
+            // accumulator register i of lane half hh is point (i&3) + 8(i>>2) + 4hh of the tile, channel 32nt + r:
+            // ascending i is ascending point index, so a strict compare keeps the first maximum
+            float bv = -INFINITY;
+            int bi = 0;
+#pragma unroll
+            for (int mt = 0; mt < TC_MT; ++mt) {
+                const int base = pt_base + mt * 32 + 4 * hh;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = acc[mt][i];
+                    const int idx = base + (i & 3) + 8 * (i >> 2);
+                    if (v > bv) {
+                        bv = v;
+                        bi = idx;
+                    }
+                }
+            }
+            bi = bi < P ? bi : P - 1;
+            const float ov = __shfl_xor(bv, 32);
+            const int oi = __shfl_xor(bi, 32);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+            if (hh == 0 && bv > s_red_wave[32 * nt + r]) {   // later passes hold later points: strict compare
+                s_red_wave[32 * nt + r] = bv;
+                s_arg_wave[32 * nt + r] = bi;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < nch; c += TC_THREADS) {
+        float bv = s_red[c];
+        int bi = s_arg[c];
+#pragma unroll
+        for (int w = 1; w < TC_WAVES; ++w) {
+            const float v = s_red[w * nch + c];
+            const int i = s_arg[w * nch + c];
+            if (v > bv || (v == bv && i < bi)) {
+                bv = v;
+                bi = i;
+            }
+        }
+        const int ch = 32 * nt0 + c;
+        bv += sh[ch];
+        pooled[(size_t)b * C3 + ch] = relu ? __builtin_fmaxf(bv, 0.f) : bv;
+        arg[(size_t)b * C3 + ch] = bi;
+    }
+}
+
+// The same product on the bfloat16 matrix pipe at float32 accuracy.  Each operand is split into three bfloat16
+// pieces, x = xh + xm + xl exactly to 2^-27 |x| (each piece is the rounded remainder of the one before), and the
+// product keeps the six of the nine piece products that are larger than 2^-27 of the whole:
+//     x w ~ xh wh + (xh wm + xm wh) + (xh wl + xm wm + xl wh)
+// Piece products are exact in the float32 accumulator, so the result differs from an exact-float32 dot product by a
+// few 2^-24 - the rounding of the accumulation itself - while six v_mfma_f32_32x32x16_bf16 (32 cycles each for
+// k = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7 times the rate.
+// (Two pieces, three products, were tried in this step and left 1.5e-5 relative: too much for BatchNorm over a
+// handful of samples.)  Same grid, tiles and epilogue as the kernel above; the weight chunks are 12 KiB.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+constexpr int TX_CHUNK_BYTES = 12288;    // half a 32-channel tile: 4 k-steps x 3 pieces x 1 KiB
+
+__device__ __forceinline__ void tx_dma_chunk(const char* src, char* dst, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int piece = wave * 3 + i;
+        __builtin_amdgcn_global_load_lds((const void*)(src + piece * 1024 + lane * 16), (lds_void*)(dst + piece * 1024),
+                                         16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(TC_THREADS, 2) void conv3_pool_train_x6_kernel(const float* __restrict__ h,
+                                                                            const unsigned short* __restrict__ w3s,
+                                                                            const float* __restrict__ sh, int P,
+                                                                            int relu, int ntb,
+                                                                            float* __restrict__ pooled,
+                                                                            int* __restrict__ arg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.x, nt0 = blockIdx.y * ntb;
+    const int nch = 32 * ntb, nchunks = 2 * ntb;
+    char* s_w3 = smem;
+    float* s_red = (float*)(smem + 2 * TX_CHUNK_BYTES);      // [4][nch]
+    int* s_arg = (int*)(s_red + TC_WAVES * nch);             // [4][nch]
+    const char* g_w3 = (const char*)w3s + (size_t)(2 * nt0) * TX_CHUNK_BYTES;
+
+    tx_dma_chunk(g_w3, s_w3, wave, lane);
+    for (int c = tid; c < TC_WAVES * nch; c += TC_THREADS) {
+        s_red[c] = -INFINITY;
+        s_arg[c] = 0;
+    }
+    __syncthreads();
+
+    float* s_red_wave = s_red + wave * nch;
+    int* s_arg_wave = s_arg + wave * nch;
+    const int pts_per_pass = TC_WAVES * 32 * TC_MT;
+    const int npass = (P + pts_per_pass - 1) / pts_per_pass;
+
+    for (int pass = 0; pass < npass; ++pass) {
+        // A operands: piece [mt][ks] of lane (r, hh) holds k = 16ks + 8hh + j of point r of tile mt
+        bf16x8 Ah[TC_MT][8], Am[TC_MT][8], Al[TC_MT][8];
+        const int pt_base = pass * pts_per_pass + wave * TC_MT * 32;
+#pragma unroll
+        for (int mt = 0; mt < TC_MT; ++mt) {
+            int pt = pt_base + mt * 32 + r;
+            pt = pt < P ? pt : P - 1;                       // duplicates of the last point cannot change a maximum
+            const float* hp = h + ((size_t)b * P + pt) * C2 + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const f32x4 v0 = *(const f32x4*)(hp + 16 * ks);
+                const f32x4 v1 = *(const f32x4*)(hp + 16 * ks + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = j < 4 ? v0[j & 3] : v1[j & 3];
+                    const __bf16 xh = (__bf16)x;
+                    const float r1 = x - (float)xh;
+                    const __bf16 xm = (__bf16)r1;
+                    Ah[mt][ks][j] = xh;
+                    Am[mt][ks][j] = xm;
+                    Al[mt][ks][j] = (__bf16)(r1 - (float)xm);
+                }
+            }
+        }
+        const bool last_pass = (pass == npass - 1);
+        for (int nt = 0; nt < ntb; ++nt) {
+            f32x16 acc[TC_MT];
+#pragma unroll
+            for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = f32x16{0};
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int ck = 2 * nt + half;
+                if (!(last_pass && ck == nchunks - 1)) {
+                    const int nxt = ck + 1 < nchunks ? ck + 1 : 0;
+                    tx_dma_chunk(g_w3 + (size_t)nxt * TX_CHUNK_BYTES, s_w3 + ((half + 1) & 1) * TX_CHUNK_BYTES, wave,
+                                 lane);
+                }
+                const char* buf = s_w3 + half * TX_CHUNK_BYTES;
+#pragma unroll
+                for (int ksl = 0; ksl < 4; ++ksl) {
+                    const int ks = 4 * half + ksl;
+                    const bf16x8 bh = *(const bf16x8*)(buf + ((ksl * 3 + 0) * 64 + lane) * 16);
+                    const bf16x8 bm = *(const bf16x8*)(buf + ((ksl * 3 + 1) * 64 + lane) * 16);
+                    const bf16x8 bl = *(const bf16x8*)(buf + ((ksl * 3 + 2) * 64 + lane) * 16);
+                    // smallest products first
+#pragma unroll
+                    for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[mt][ks], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[mt][ks], bm, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[mt][ks], bl, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[mt][ks], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[mt][ks], bm, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[mt][ks], bh, acc[mt], 0, 0, 0);
                 }
                 __syncthreads();
             }
@@ -641,7 +822,7 @@ hipError_t t_conv3_fwd(float* h2, const float* W3, const float* b3, const float*
     hipLaunchKernelGGL(k_gram_finalize, dim3(C2 * C2 / 16), dim3(256), 0, s, (const double*)gram_part, chunks,
                        (const double*)w.abar_d, M, w.cov);
     hipLaunchKernelGGL(k_conv3_stats_pack, dim3(C3), dim3(128), 0, s, W3, b3, gamma, beta, (const double*)w.cov,
-                       (const double*)w.abar_d, M, momentum, mean, rstd, running_mean, running_var, w.w3p, w.sh);
+                       (const double*)w.abar_d, M, momentum, mean, rstd, running_mean, running_var, w.w3p, w.w3s, w.sh);
     // enough workgroups for two per CU: split the channels of a candidate when the batch is small
     // (B = 256 on 256 CUs: 444 / 408 / 422 / 458 us with 1 / 2 / 4 / 8 pieces)
     int dev = 0, n_cu = 0;
@@ -652,12 +833,24 @@ hipError_t t_conv3_fwd(float* h2, const float* W3, const float* b3, const float*
     int cs = 1;
     while (cs < 8 && B * cs < 2 * n_cu) cs *= 2;
     const int ntb = 32 / cs;
-    const size_t lds = 2 * TC_CHUNK_BYTES + (size_t)TC_WAVES * 32 * ntb * 8;
-    e = hipFuncSetAttribute((const void*)conv3_pool_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    if (w.ev_begin != nullptr && (e = hipEventRecord(w.ev_begin, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(conv3_pool_train_kernel, dim3(B, cs), dim3(TC_THREADS), lds, s, h2, (const float*)w.w3p,
-                       (const float*)w.sh, P, relu_out, ntb, pooled, arg);
+    // PNGPD_TRAIN_CONV3=f32 keeps the product on the float32 matrix instruction (the split-bfloat16 form is the default)
+    static const bool use_f32 = [] { const char* v = getenv("PNGPD_TRAIN_CONV3"); return v && v[0] == 'f'; }();
+    if (use_f32 || w.w3s == nullptr) {
+        const size_t lds = 2 * TC_CHUNK_BYTES + (size_t)TC_WAVES * 32 * ntb * 8;
+        e = hipFuncSetAttribute((const void*)conv3_pool_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (w.ev_begin != nullptr && (e = hipEventRecord(w.ev_begin, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(conv3_pool_train_kernel, dim3(B, cs), dim3(TC_THREADS), lds, s, h2, (const float*)w.w3p,
+                           (const float*)w.sh, P, relu_out, ntb, pooled, arg);
+    } else {
+        const size_t lds = 2 * TX_CHUNK_BYTES + (size_t)TC_WAVES * 32 * ntb * 8;
+        e = hipFuncSetAttribute((const void*)conv3_pool_train_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        if (e != hipSuccess) return e;
+        if (w.ev_begin != nullptr && (e = hipEventRecord(w.ev_begin, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(conv3_pool_train_x6_kernel, dim3(B, cs), dim3(TC_THREADS), lds, s, h2,
+                           (const unsigned short*)w.w3s, (const float*)w.sh, P, relu_out, ntb, pooled, arg);
+    }
     if (w.ev_end != nullptr && (e = hipEventRecord(w.ev_end, s)) != hipSuccess) return e;
     return hipGetLastError();
 }

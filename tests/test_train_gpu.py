@@ -79,32 +79,18 @@ def test_autograd_path_matches_reference_golden_step():
 
 
 def test_fused_trainer_matches_autograd_path_and_oracle():
-    """Two fused steps.  Step 1 is compared with the oracle from the same initial state.  Adam's first update is
-    lr*sign(g), so the trajectories of two implementations part wherever a gradient is rounding noise; step 2 is
-    therefore compared with an oracle that starts from the HIP model's OWN state after step 1 (parameters, running
-    statistics and Adam moments): per-step parity, which is what a drop-in has to offer."""
+    """Two fused steps (forward, NLL, backward, Adam), each compared with a float64 step of the restated network that
+    starts from the HIP model's own state (parameters, running statistics, Adam moments - per-step parity, which is
+    what a drop-in has to offer) and is forced onto the decisions the HIP forward took (arg-max rows, ReLU masks;
+    checked to be right to rounding): loss, every gradient, the post-Adam parameters and the running statistics.
+    A plain float32 reference cannot arbitrate here: with 10^4 max decisions per step one is usually tied to within
+    float32 rounding, and then two correct implementations route that gradient to different rows."""
+    from pointnetgpd_amd import training
     P, k, seed, B = 500, 3, 77, 6
     gain = 1.7
     x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
     target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) * k).astype(np.int64))
     sd0 = synth.torch_state_dict(seed, k, 1.0, gain)
-
-    def oracle_step(sd, moments, dtype=torch.float32):
-        oracle = po.build_cls(P, k, sd, eval_mode=False).to(dtype)
-        oopt = torch.optim.Adam(oracle.parameters(), lr=0.005)
-        if moments is not None:
-            for n, p in oracle.named_parameters():
-                m1, m2 = moments[n]
-                oopt.state[p] = {"step": torch.tensor(1.0), "exp_avg": m1.view_as(p).clone().to(dtype),
-                                 "exp_avg_sq": m2.view_as(p).clone().to(dtype)}
-        oopt.zero_grad()
-        out, _ = oracle(x.to(dtype))
-        l = F.nll_loss(out, target)
-        l.backward()
-        grads = {n: p.grad.clone() for n, p in oracle.named_parameters()}
-        oopt.step()
-        return l.item(), oracle.state_dict(), grads
-
     m = PointNetCls(P, 3, k)
     m.load_state_dict(sd0)
     m = m.cuda().train()
@@ -118,65 +104,55 @@ def test_fused_trainer_matches_autograd_path_and_oracle():
             off += n
         return out
 
-    def compare(ref_sd, grads, atol):
-        got_sd = m.state_dict()
-        for n in ("fc3.weight", "fc3.bias", "feat.stn.fc3.weight", "fc1.weight", "feat.conv3.weight",
-                  "feat.stn.conv3.weight", "feat.conv2.weight", "feat.bn3.weight"):
-            # skip |g| ~ 0: there the update lr*g/(|g| + eps) is a sign of noise, and just above it the eps term
-            # still turns a 1e-5 absolute gradient difference into a 1e-5 parameter difference
-            clear = grads[n].abs() > 1e-4
-            diff = (got_sd[n].cpu() - ref_sd[n]).abs()[clear]
-            assert float(diff.max()) < atol, (n, float(diff.max()))
+    def hip_grads():
+        out, off = {}, 0
+        for name, p in m.named_parameters():
+            out[name] = tr.flat_g[off:off + p.numel()].cpu().view_as(p).double()
+            off += p.numel()
+        return out
+
+    for step in (1, 2):
+        sd = {n: v.detach().cpu().clone() for n, v in m.state_dict().items()}
+        moments = hip_moments() if step > 1 else None
+        loss = tr.step(x.cuda(), target.cuda())[0].item()
+        ws = tr._ws                                    # holds the decisions of the forward of this step
+        arg_stn, arg_trunk = (a.cpu() for a in training.critical_points(ws, B, P, k))
+        masks = {n: (training.saved_activation(ws, B, P, k, n) > 0).cpu() for n in training.SAVED}
+        o = po.build_cls(P, k, sd, eval_mode=False).double()
+        opt = torch.optim.Adam(o.parameters(), lr=0.005)
+        if moments is not None:
+            for n, p in o.named_parameters():
+                opt.state[p] = {"step": torch.tensor(float(step - 1)), "exp_avg": moments[n][0].view_as(p).double(),
+                                "exp_avg_sq": moments[n][1].view_as(p).double()}
+        ref_logp, kinks, pools = forced_forward(o, x.double(), arg_stn, arg_trunk, masks)
+        for chosen, true_max in pools:                 # the chosen row holds the maximum
+            assert float((true_max - chosen).detach().max()) < 2e-6 * float(true_max.detach().abs().max())
+        for pre, mask in kinks:                        # a mask differs from the float64 sign only at ~0
+            wrong = (pre.detach() > 0) != mask
+            if wrong.any():
+                assert float(pre.detach()[wrong].abs().max()) < 2e-5 * float(pre.detach().abs().max())
+        ref_loss = F.nll_loss(ref_logp, target)
+        ref_loss.backward()
+        assert abs(loss - ref_loss.item()) < 2e-5 * max(1.0, abs(ref_loss.item()))
+        g64 = {n: p.grad.clone() for n, p in o.named_parameters()}
+        opt.step()
+        gh, got_sd, ref_sd = hip_grads(), m.state_dict(), o.state_dict()
+        worst_g = worst_p = 0.0
+        for n, g in g64.items():
+            scale = float(g.abs().max())
+            if scale < 1e-7:
+                assert float(gh[n].abs().max()) < 1e-5, n
+                continue
+            worst_g = max(worst_g, float((gh[n] - g).abs().max()) / scale)
+            clear = g.abs() > 1e-4                    # below that the Adam update is the sign of rounding noise
+            if clear.any():
+                worst_p = max(worst_p, float((got_sd[n].cpu().double() - ref_sd[n]).abs()[clear].max()))
+        print(f"step {step}: gradients within {worst_g:.2e} of each tensor's largest entry, post-Adam parameters "
+              f"within {worst_p:.2e} of the float64 step")
+        assert worst_g < 1e-4 and worst_p < 5e-6, (step, worst_g, worst_p)
         for n in ref_sd:
             if n.endswith(("running_mean", "running_var")):
                 np.testing.assert_allclose(got_sd[n].cpu().numpy(), ref_sd[n].numpy(), rtol=2e-4, atol=2e-5, err_msg=n)
-
-    # step 1
-    loss_ref, ref_sd, grads = oracle_step(sd0, None)
-    loss = tr.step(x.cuda(), target.cuda())[0].item()
-    assert abs(loss - loss_ref) < 2e-5
-    compare(ref_sd, grads, 2e-5)
-    # step 2, from the HIP model's own state, three ways: the fused trainer, the float32 oracle and the SAME oracle in
-    # float64 (parameters, running statistics and Adam moments converted exactly).  The float64 step is the arbiter:
-    # the trainer must be as close to it as the float32 oracle is, parameter by parameter (measured on MI355X: both
-    # within 1e-6 of it after Adam, gradients within 5e-6 of each tensor's largest entry).
-    sd1 = {n: v.detach().cpu().clone() for n, v in m.state_dict().items()}
-    mom = hip_moments()
-    loss_ref, ref_sd, grads = oracle_step(sd1, mom)
-    loss64, ref64_sd, grads64 = oracle_step(sd1, mom, torch.float64)
-    loss = tr.step(x.cuda(), target.cuda())[0].item()
-    assert abs(loss - loss64) < 2e-5 * max(1.0, abs(loss64)) and abs(loss_ref - loss64) < 2e-5 * max(1.0, abs(loss64))
-    got_sd = m.state_dict()
-    report = []
-    for n, g64 in grads64.items():
-        clear = g64.abs() > 1e-4          # below that the Adam update is the sign of rounding noise
-        if not clear.any():
-            continue
-        e_hip = float((got_sd[n].cpu().double() - ref64_sd[n]).abs()[clear].max())
-        e_o32 = float((ref_sd[n].double() - ref64_sd[n]).abs()[clear].max())
-        report.append((n, e_hip, e_o32))
-    # gradients of the same step, relative to the largest entry of each tensor
-    gh, off = {}, 0
-    for n, p in m.named_parameters():
-        gh[n] = tr.flat_g[off:off + p.numel()].cpu().view_as(p).double()
-        off += p.numel()
-    worst_hip = worst_o32 = 0.0
-    for n, g64 in grads64.items():
-        scale = float(g64.abs().max())
-        if scale < 1e-5:
-            continue
-        worst_hip = max(worst_hip, float((gh[n] - g64).abs().max()) / scale)
-        worst_o32 = max(worst_o32, float((grads[n].double() - g64).abs().max()) / scale)
-    print(f"step 2 gradients vs float64, relative to each tensor's largest entry: trainer {worst_hip:.2e}, "
-          f"float32 oracle {worst_o32:.2e}")
-    for n, e_hip, e_o32 in report:
-        print(f"  {n:28s} post-Adam parameter error vs float64: trainer {e_hip:.2e}  float32 oracle {e_o32:.2e}")
-    assert worst_hip <= max(3.0 * worst_o32, 2e-5), (worst_hip, worst_o32)
-    for n, e_hip, e_o32 in report:
-        assert e_hip <= max(3.0 * e_o32, 2e-6) and e_hip < 5e-6, (n, e_hip, e_o32)
-    for n in ref_sd:
-        if n.endswith(("running_mean", "running_var")):
-            np.testing.assert_allclose(got_sd[n].cpu().numpy(), ref64_sd[n].numpy(), rtol=2e-4, atol=2e-5, err_msg=n)
     # eval after training must re-fold / re-pack the weights the fused update wrote: compare with the
     # oracle evaluated on the HIP model's OWN post-training state_dict
     m.eval()
@@ -252,11 +228,11 @@ def test_every_gradient_against_oracle():
 
 @pytest.mark.parametrize("P,B,k,seed", [(5, 16, 2, 5), (40, 8, 3, 6), (257, 9, 2, 7)])
 def test_gradients_and_statistics_at_odd_shapes(P, B, k, seed):
-    """Shapes that leave point tiles, channel splits and per-wave row ranges of the conv3 path partly empty.
-    (The max over points and the ReLUs make the gradient discontinuous: where two points tie, or a pre-activation
-    sits at zero, to within float32 rounding, two correct float32 implementations differ in isolated elements.
-    These small seeded cases stay clear of that; larger ones are covered by the tie-proof test below, and
-    tests/diag_train_step.py compares both implementations with a float64 step.)"""
+    """Shapes that leave point tiles, channel splits and per-wave row ranges of the conv3 path partly empty: the
+    continuous outputs (log-probabilities, transform, running statistics) against the float32 oracle.  The gradients
+    of these shapes are checked in test_gradients_with_the_kernels_own_decisions: the max over points and the ReLUs
+    make them discontinuous, and where two points tie to within float32 rounding two correct implementations route
+    the gradient to different rows (P=257, B=9: the float32 oracle itself is 1.5e-3 away from a float64 step)."""
     gain = 1.3
     x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
     target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) * k).astype(np.int64))
@@ -269,13 +245,7 @@ def test_gradients_and_statistics_at_odd_shapes(P, B, k, seed):
     F.nll_loss(out2, target.cuda()).backward()
     np.testing.assert_allclose(out2.detach().cpu().numpy(), out.detach().numpy(), atol=1e-4)
     np.testing.assert_allclose(trans2.detach().cpu().numpy(), trans.detach().numpy(), atol=1e-4)
-    ref = {n: p.grad.numpy() for n, p in oracle.named_parameters()}
-    for n, p in m.named_parameters():
-        g = p.grad.cpu().numpy()
-        if np.abs(ref[n]).max() < 1e-5:
-            assert np.abs(g).max() < 1e-5, n
-        else:
-            assert rel_err(g, ref[n]) < 3e-3, (n, rel_err(g, ref[n]))
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
     ref_sd, got_sd = oracle.state_dict(), m.state_dict()
     for n in ref_sd:
         if n.endswith(("running_mean", "running_var")):
@@ -352,7 +322,8 @@ def forced_forward(o, x, arg_stn, arg_trunk, masks):
 
 
 @pytest.mark.parametrize("P,B,k,seed", [(130, 70, 2, 8), (64, 70, 2, 8), (64, 70, 2, 13), (37, 150, 2, 9),
-                                        (300, 20, 3, 10), (750, 24, 2, 11), (750, 256, 2, 12)])
+                                        (300, 20, 3, 10), (750, 24, 2, 11), (750, 256, 2, 12),
+                                        (5, 16, 2, 5), (40, 8, 3, 6), (257, 9, 2, 7), (500, 6, 3, 77)])
 def test_gradients_with_the_kernels_own_decisions(P, B, k, seed):
     """A PointNet step is piecewise smooth: the max over points and every ReLU switch where two values tie to within
     float32 rounding, and with ~10^6 such decisions per step a few always do.  Two correct float32 implementations
