@@ -25,11 +25,14 @@ _DEFAULT_PRECISION = os.environ.get("PNGPD_PRECISION", "fp32")
 # Bumped whenever library kernels change parameters or running statistics behind torch's back
 # (training step, fused Adam): torch's per-tensor version counters do not see those writes.
 _GENERATION = [0]
+# Bumped whenever the tensors of a module may have been replaced (see _HipBacked._weights_signature).
+_STRUCTURE = [0]
 
 
 def invalidate_packed_weights() -> None:
     """Force every module to re-fold and re-pack its weights on the next eval-mode forward."""
     _GENERATION[0] += 1
+    _STRUCTURE[0] += 1
 
 
 class _Handle:
@@ -87,11 +90,42 @@ class _HipBacked(nn.Module):
             if bn is not None:
                 yield from (bn.weight, bn.bias, bn.running_mean, bn.running_var)
 
+    # ---- when do the packed device weights have to be rebuilt? -------------------------------------------------
+    # Values change in place (optimizer steps, load_state_dict, manual edits under no_grad): every such write bumps
+    # the tensor's autograd version counter, and the counters of the module's tensors are polled on every forward -
+    # one attribute read each, from a cached list.  The tensors THEMSELVES change (another storage or another
+    # Parameter object) through .to() / .cuda() / .float() (nn.Module._apply), load_state_dict(assign=True) or by
+    # assigning a new sub-module or Parameter to a module of this package; those paths bump _STRUCTURE below, which
+    # drops the cached list.  What nothing here can see is a Parameter assigned straight onto a plain torch layer
+    # (`model.fc3.weight = nn.Parameter(...)`): call invalidate_packed_weights() after that.
+    def _apply(self, fn, *args, **kwargs):
+        _STRUCTURE[0] += 1
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        _STRUCTURE[0] += 1
+        return super().load_state_dict(*args, **kwargs)
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Module, torch.Tensor)):
+            _STRUCTURE[0] += 1
+        super().__setattr__(name, value)
+
+    def _weights_signature(self):
+        cache = self.__dict__.get("_sig_cache")
+        if cache is None or cache[0] != _STRUCTURE[0]:
+            tensors = list(self._tensors())
+            cache = self.__dict__["_sig_cache"] = (_STRUCTURE[0], tensors, tuple(t.data_ptr() for t in tensors))
+        versions = 0
+        for t in cache[1]:
+            versions += t._version
+        return (_GENERATION[0], versions, cache[2])
+
     def _handle(self, device: torch.device) -> _Handle:
         h = self.__dict__.get("_hip")
         if h is None or h.device != device:
             h = self.__dict__["_hip"] = _Handle(device, self.num_points, self._num_classes(), self._PARTS)
-        sig = (_GENERATION[0],) + tuple((t.data_ptr(), t._version) for t in self._tensors())
+        sig = self._weights_signature()
         if h.signature != sig:
             self._upload(h)
             h.signature = sig
@@ -100,7 +134,7 @@ class _HipBacked(nn.Module):
     def _upload(self, h: _Handle) -> None:
         units = self._units()
         table = (ctypes.c_void_p * _lib.SLOTS)()
-        keep = []
+        slots, parts = [], []
         for ui, uname in enumerate(_lib.UNITS):
             if uname not in units:
                 continue
@@ -108,11 +142,15 @@ class _HipBacked(nn.Module):
             fields = [layer.weight, layer.bias]
             fields += [bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [None] * 4
             for fi, t in enumerate(fields):
-                if t is None:
-                    continue
-                host = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
-                keep.append(host)
-                table[ui * len(_lib.FIELDS) + fi] = host.data_ptr()
+                if t is not None:
+                    slots.append(ui * len(_lib.FIELDS) + fi)
+                    parts.append(t.detach().to(torch.float32).reshape(-1))
+        # one device-to-host transfer for all tensors (68 separate ones cost a synchronisation each)
+        host = torch.cat(parts).cpu()
+        off = 0
+        for slot, part in zip(slots, parts):
+            table[slot] = host.data_ptr() + 4 * off
+            off += part.numel()
         with torch.cuda.device(h.device):
             stream = torch.cuda.current_stream(h.device).cuda_stream
             _lib.check(h.lib.pngpd_model_load(h.ptr, table, _lib.SLOTS, ctypes.c_void_p(stream)))
@@ -145,14 +183,18 @@ class _HipBacked(nn.Module):
         feat = torch.empty((B, 1024), dtype=torch.float32, device=dev) if want_feat else None
         trans = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
         ws = h.workspace(B)
+        if torch.cuda.current_device() != dev.index:      # the library works on the current device
+            with torch.cuda.device(dev):
+                return self._launch(h, x, layout, B, prec, logp, trans, feat, ws)
+        return self._launch(h, x, layout, B, prec, logp, trans, feat, ws)
 
-        def p(t):
-            return ctypes.c_void_p(t.data_ptr()) if t is not None else None
-
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(h.lib.pngpd_forward_infer(h.ptr, p(x), layout, B, self.num_points, prec, p(logp), p(trans),
-                                                 p(feat), p(ws), ws.numel(), ctypes.c_void_p(stream)))
+    def _launch(self, h, x, layout, B, prec, logp, trans, feat, ws):
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = h.lib.pngpd_forward_infer(h.ptr, x.data_ptr(), layout, B, self.num_points, prec,
+                                       logp.data_ptr() if logp is not None else None, trans.data_ptr(),
+                                       feat.data_ptr() if feat is not None else None, ws.data_ptr(), ws.numel(), stream)
+        if rc != _lib.OK:
+            _lib.check(rc)
         return logp, trans, feat
 
 
