@@ -283,6 +283,13 @@ int pngpd_train_forward(int B, int P, int k, const float* x_dev, float* const* p
                         int n_slots, float momentum, float* logp_dev, float* trans_dev,
                         float* feat_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* The same forward for a model that owns only some parts (PNGPD_PART_*; STN, STN|TRUNK or all three): the train-mode
+ * forward of a standalone STN3d (model/pointnet.py:28-45 -> trans_dev) or PointNetfeat (:135-149 -> feat_dev,
+ * trans_dev).  Units of params_dev outside `parts` may be NULL; logp_dev is needed only with the head. */
+int pngpd_train_forward_parts(int parts, int B, int P, int k, const float* x_dev, float* const* params_dev,
+                              int n_slots, float momentum, float* logp_dev, float* trans_dev, float* feat_dev,
+                              void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* The point index that holds each channel's maximum in the two MaxPool1d(num_points) of the last
  * pngpd_train_forward on this workspace (model/pointnet.py:33 in the STN, :147 in the trunk; the first
  * maximum, as max_pool1d reports it): int32 [B,1024] each, either pointer may be NULL.  These are the
@@ -319,11 +326,15 @@ int pngpd_train_backward(int B, int P, int k, const float* x_dev, const float* c
  * input gradient the one before left in the workspace.  After a call returns, the gradients of its parts (HEAD:
  * units FC1..FC3; TRUNK: FEAT_CONV1..3; STN: STN_CONV1..STN_FC3) are final in stream order.  HEAD | TRUNK | STN in
  * one call is pngpd_train_backward.
+ * The same entry point is the backward pass of a model without a head (pngpd_train_forward_parts): parts =
+ * TRUNK | STN with dfeat_dev [B,1024], the gradient w.r.t. the global feature (logp_dev / dlogp_dev NULL), or parts
+ * = STN with dtrans_dev alone.  dfeat_dev must be NULL when the head is among the parts; with TRUNK but neither
+ * HEAD nor dfeat_dev the trunk takes the feature gradient an earlier HEAD call left in the workspace.
  */
 int pngpd_train_backward_part(int B, int P, int k, const float* x_dev, const float* const* params_dev,
                               float* const* grads_dev, int n_slots, const float* logp_dev,
-                              const float* dlogp_dev, const float* dtrans_dev, void* workspace_dev,
-                              size_t workspace_bytes, int parts, void* stream);
+                              const float* dlogp_dev, const float* dtrans_dev, const float* dfeat_dev,
+                              void* workspace_dev, size_t workspace_bytes, int parts, void* stream);
 
 /* F.nll_loss(logp, target) with mean reduction (main_1v.py:270): loss_dev[1] and its gradient
  * dlogp_dev [B,k].  target_dev int64 [B].  A label outside [0,k), on which F.nll_loss raises, is not used as an

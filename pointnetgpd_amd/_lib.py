@@ -70,7 +70,9 @@ SIGNATURES = {
     "pngpd_train_backward": (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pngpd_train_backward_part": (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int,
-                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "pngpd_train_forward_parts": (c_int, [c_int, c_int, c_int, c_int, c_void_p, POINTER(c_void_p), c_int, c_float,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pngpd_train_saved": (c_int, [c_int, c_int, c_int, c_void_p, c_size_t, c_int, POINTER(c_void_p), POINTER(c_size_t)]),
     "pngpd_train_argmax": (c_int, [c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "pngpd_nll_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

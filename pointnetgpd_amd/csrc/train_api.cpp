@@ -116,8 +116,16 @@ struct TrainWs {
 inline float* slot(float* const* t, int unit, int field) { return t[unit * PNGPD_FIELDS + field]; }
 inline const float* cslot(const float* const* t, int unit, int field) { return t[unit * PNGPD_FIELDS + field]; }
 
-int check_tables(float* const* params, bool need_running) {
+// units a model with these parts owns: STN 0..5, trunk 6..8, head 9..11
+inline bool unit_in_parts(int u, int parts) {
+    if (u <= PNGPD_U_STN_FC3) return parts & PNGPD_PART_STN;
+    if (u <= PNGPD_U_FEAT_CONV3) return parts & PNGPD_PART_TRUNK;
+    return parts & PNGPD_PART_HEAD;
+}
+
+int check_tables(float* const* params, bool need_running, int parts) {
     for (int u = 0; u < PNGPD_UNITS; ++u) {
+        if (!unit_in_parts(u, parts)) continue;
         const bool has_bn = (u != PNGPD_U_STN_FC3 && u != PNGPD_U_FC3);
         if (!slot(params, u, PNGPD_F_WEIGHT) || !slot(params, u, PNGPD_F_BIAS))
             return fail(PNGPD_ERR_INVALID, "training table: unit %d has no weight/bias", u);
@@ -236,14 +244,23 @@ size_t pngpd_train_workspace_bytes(int B, int P, int k) {
 }
 
 // ev: nullptr, or 4 events recorded around the conv3 product/max kernel of the STN (0,1) and the trunk (2,3)
+static int valid_model_parts(int parts) {
+    const int all = PNGPD_PART_STN | PNGPD_PART_TRUNK | PNGPD_PART_HEAD;
+    return parts == PNGPD_PART_STN || parts == (PNGPD_PART_STN | PNGPD_PART_TRUNK) || parts == all;
+}
+
 static int train_forward_impl(int B, int P, int k, const float* x_dev, float* const* params_dev, int n_slots,
                               float momentum, float* logp_dev, float* trans_dev, float* feat_dev, void* workspace_dev,
-                              size_t workspace_bytes, void* stream, hipEvent_t* ev) {
-    if (!x_dev || !params_dev || !logp_dev) return fail(PNGPD_ERR_INVALID, "pngpd_train_forward: NULL argument");
+                              size_t workspace_bytes, void* stream, hipEvent_t* ev,
+                              int parts = PNGPD_PART_STN | PNGPD_PART_TRUNK | PNGPD_PART_HEAD) {
+    if (!x_dev || !params_dev) return fail(PNGPD_ERR_INVALID, "pngpd_train_forward: NULL argument");
+    if (!valid_model_parts(parts))
+        return fail(PNGPD_ERR_INVALID, "parts must be STN, STN|TRUNK or STN|TRUNK|HEAD, got %d", parts);
+    if ((parts & PNGPD_PART_HEAD) && !logp_dev) return fail(PNGPD_ERR_INVALID, "pngpd_train_forward: NULL logp_dev");
     if (n_slots != PNGPD_SLOTS) return fail(PNGPD_ERR_INVALID, "training table must have %d slots", PNGPD_SLOTS);
     int rc = check_shape(B, P, k, workspace_dev, workspace_bytes);
     if (rc) return rc;
-    if ((rc = check_tables(params_dev, true))) return rc;
+    if ((rc = check_tables(params_dev, true, parts))) return rc;
     hipStream_t s = (hipStream_t)stream;
     TrainWs W(workspace_dev, B, P, k);
     if (ev) {
@@ -258,9 +275,15 @@ static int train_forward_impl(int B, int P, int k, const float* x_dev, float* co
     if ((rc = fwd_fc(W.stn_fc, params_dev, PNGPD_U_STN_FC1, W.stn.pooled, trans, B, 9, pngpd::FC_TAIL_ADD_IDENTITY,
                      momentum, W.part, W.fc_part, s)))
         return rc;
+    if (!(parts & PNGPD_PART_TRUNK)) return PNGPD_OK;
     if ((rc = fwd_stack(W.trunk, params_dev, PNGPD_U_FEAT_CONV1, x_dev, trans, B, P, 0, momentum, W.part, W.gram_part,
                        s)))
         return rc;
+    if (!(parts & PNGPD_PART_HEAD)) {
+        if (feat_dev)
+            HIP_TRY(hipMemcpyAsync(feat_dev, W.trunk.pooled, (size_t)B * C3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return PNGPD_OK;
+    }
     if ((rc = fwd_fc(W.head_fc, params_dev, PNGPD_U_FC1, W.trunk.pooled, logp_dev, B, k, pngpd::FC_TAIL_LOG_SOFTMAX,
                      momentum, W.part, W.fc_part, s)))
         return rc;
@@ -274,6 +297,13 @@ int pngpd_train_forward(int B, int P, int k, const float* x_dev, float* const* p
                         size_t workspace_bytes, void* stream) {
     return train_forward_impl(B, P, k, x_dev, params_dev, n_slots, momentum, logp_dev, trans_dev, feat_dev,
                               workspace_dev, workspace_bytes, stream, nullptr);
+}
+
+int pngpd_train_forward_parts(int parts, int B, int P, int k, const float* x_dev, float* const* params_dev, int n_slots,
+                              float momentum, float* logp_dev, float* trans_dev, float* feat_dev, void* workspace_dev,
+                              size_t workspace_bytes, void* stream) {
+    return train_forward_impl(B, P, k, x_dev, params_dev, n_slots, momentum, logp_dev, trans_dev, feat_dev,
+                              workspace_dev, workspace_bytes, stream, nullptr, parts);
 }
 
 int pngpd_train_forward_timed(int B, int P, int k, const float* x_dev, float* const* params_dev, int n_slots,
@@ -339,16 +369,19 @@ int pngpd_train_saved(int B, int P, int k, const void* workspace_dev, size_t wor
 static int train_backward_impl(int B, int P, int k, const float* x_dev, const float* const* params_dev,
                                float* const* grads_dev, int n_slots, const float* logp_dev, const float* dlogp_dev,
                                const float* dtrans_dev, void* workspace_dev, size_t workspace_bytes, int parts,
-                               void* stream) {
-    if (!x_dev || !params_dev || !grads_dev || !logp_dev || !dlogp_dev)
-        return fail(PNGPD_ERR_INVALID, "pngpd_train_backward: NULL argument");
+                               void* stream, const float* dfeat_dev = nullptr) {
+    if (!x_dev || !params_dev || !grads_dev) return fail(PNGPD_ERR_INVALID, "pngpd_train_backward: NULL argument");
+    if ((parts & PNGPD_PART_HEAD) && (!logp_dev || !dlogp_dev))
+        return fail(PNGPD_ERR_INVALID, "pngpd_train_backward: the head part needs logp_dev and dlogp_dev");
+    if ((parts & PNGPD_PART_HEAD) && dfeat_dev)
+        return fail(PNGPD_ERR_INVALID, "pngpd_train_backward: dfeat_dev is the input gradient of a model without a head");
     if (n_slots != PNGPD_SLOTS) return fail(PNGPD_ERR_INVALID, "training table must have %d slots", PNGPD_SLOTS);
     const int all = PNGPD_PART_STN | PNGPD_PART_TRUNK | PNGPD_PART_HEAD;
     if (parts == 0 || (parts & ~all)) return fail(PNGPD_ERR_INVALID, "pngpd_train_backward_part: bad part mask %d", parts);
     int rc = check_shape(B, P, k, workspace_dev, workspace_bytes);
     if (rc) return rc;
-    if ((rc = check_tables((float* const*)params_dev, false))) return rc;
-    if ((rc = check_tables(grads_dev, false))) return rc;
+    if ((rc = check_tables((float* const*)params_dev, false, parts))) return rc;
+    if ((rc = check_tables(grads_dev, false, parts))) return rc;
     hipStream_t s = (hipStream_t)stream;
     TrainWs W(workspace_dev, B, P, k);
     if (parts & PNGPD_PART_HEAD) {
@@ -356,9 +389,15 @@ static int train_backward_impl(int B, int P, int k, const float* x_dev, const fl
         if ((rc = bwd_fc(W.head_fc, params_dev, grads_dev, PNGPD_U_FC1, W.trunk.pooled, W.dlogits, B, k, W, s))) return rc;
     }
     if (parts & PNGPD_PART_TRUNK) {
-        if ((rc = bwd_stack(W.trunk, params_dev, grads_dev, PNGPD_U_FEAT_CONV1, W.head_fc.din, B, P, 0, true, W, s)))
+        // the gradient of the pooled feature: the caller's (a model without a head), else what the head's backward
+        // pass - this call's or an earlier one's - left in the workspace
+        const float* dpooled = dfeat_dev ? dfeat_dev : W.head_fc.din;
+        if ((rc = bwd_stack(W.trunk, params_dev, grads_dev, PNGPD_U_FEAT_CONV1, dpooled, B, P, 0, true, W, s)))
             return rc;
         HIP_TRY(pngpd::t_trans_grad(x_dev, W.trunk.dX3, B, P, dtrans_dev, W.dtrans, s));
+    } else if (parts == PNGPD_PART_STN && dtrans_dev) {
+        // transform regressor alone: the gradient of its output is the caller's
+        HIP_TRY(hipMemcpyAsync(W.dtrans, dtrans_dev, (size_t)B * 9 * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     if (parts & PNGPD_PART_STN) {
         if ((rc = bwd_fc(W.stn_fc, params_dev, grads_dev, PNGPD_U_STN_FC1, W.stn.pooled, W.dtrans, B, 9, W, s))) return rc;
@@ -378,10 +417,10 @@ int pngpd_train_backward(int B, int P, int k, const float* x_dev, const float* c
 
 int pngpd_train_backward_part(int B, int P, int k, const float* x_dev, const float* const* params_dev,
                               float* const* grads_dev, int n_slots, const float* logp_dev, const float* dlogp_dev,
-                              const float* dtrans_dev, void* workspace_dev, size_t workspace_bytes, int parts,
-                              void* stream) {
+                              const float* dtrans_dev, const float* dfeat_dev, void* workspace_dev,
+                              size_t workspace_bytes, int parts, void* stream) {
     return train_backward_impl(B, P, k, x_dev, params_dev, grads_dev, n_slots, logp_dev, dlogp_dev, dtrans_dev,
-                               workspace_dev, workspace_bytes, parts, stream);
+                               workspace_dev, workspace_bytes, parts, stream, dfeat_dev);
 }
 
 int pngpd_nll_loss(const float* logp_dev, const int64_t* target_dev, int B, int k, float* loss_dev, float* dlogp_dev,

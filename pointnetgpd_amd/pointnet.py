@@ -161,9 +161,6 @@ class _HipBacked(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("pointnetgpd_amd runs on MI355X only: move the module and its input to a "
                                "ROCm device (there is no CPU path)")
-        if self.training:
-            raise RuntimeError("train-mode forward (batch statistics) is implemented for PointNetCls as a whole "
-                               "(pointnetgpd_amd.training); call .eval() for inference")
         chan_dim, pts_dim = (1, 2) if layout == _lib.LAYOUT_C3P else (2, 1)
         if x.shape[chan_dim] != 3:
             raise ValueError(f"input_chann must be 3, got {x.shape[chan_dim]}")
@@ -225,6 +222,9 @@ class STN3d(_HipBacked):
     _units = _stn_units
 
     def forward(self, x):
+        if self.training:                       # batch-statistics BatchNorm + autograd
+            from .training import forward_train_mode
+            return forward_train_mode(self, x)
         return self._infer(x, _lib.LAYOUT_C3P, False, False)[1]
 
 
@@ -255,6 +255,9 @@ class PointNetfeat(_HipBacked):
         if not self.global_feat:
             raise NotImplementedError("global_feat=False (per-point features for PointNetDenseCls) is not "
                                       "part of the grasp-scoring path")
+        if self.training:                       # batch-statistics BatchNorm + autograd
+            from .training import forward_train_mode
+            return forward_train_mode(self, x)
         _, trans, feat = self._infer(x, _lib.LAYOUT_C3P, False, True)
         return feat, trans
 

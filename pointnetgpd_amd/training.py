@@ -33,6 +33,9 @@ def _unit_tensors(model):
     out = []
     units = model._units()
     for uname in _lib.UNITS:
+        if uname not in units:                 # a model without this part (standalone STN3d / PointNetfeat)
+            out.append([None] * 6)
+            continue
         layer, bn = units[uname]
         row = [layer.weight, layer.bias]
         row += [bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [None] * 4
@@ -67,35 +70,46 @@ def _check(model, x):
     return x.detach().to(torch.float32).contiguous()
 
 
+def _classes(model):
+    return model.fc3.out_features if (model._PARTS & _lib.PART_HEAD) else 2     # unused without a head
+
+
 def train_forward(model, x, ws=None, conv3_ms=None):
-    """Train-mode forward; returns (logp, trans, workspace, x).  Updates running statistics.
+    """Train-mode forward of a PointNetCls, PointNetfeat or STN3d; returns (logp, trans, workspace, x) - for a model
+    without a head (logp is None then) followed by feat.  Updates running statistics.
     conv3_ms: a list that receives the durations (ms, HIP events) of the two conv3 product/max kernels."""
     lib = _lib.load()
     x = _check(model, x)
     B, _, P = x.shape
-    k = model.fc3.out_features
+    parts = model._PARTS
+    k = _classes(model)
     dev = x.device
     nbytes = lib.pngpd_train_workspace_bytes(B, P, k)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     rows = _unit_tensors(model)
     params = _table(rows, lambda t, fi: t.data)
-    logp = torch.empty((B, k), dtype=torch.float32, device=dev)
+    logp = torch.empty((B, k), dtype=torch.float32, device=dev) if parts & _lib.PART_HEAD else None
     trans = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
+    feat = torch.empty((B, 1024), dtype=torch.float32, device=dev) if parts == (_lib.PART_STN | _lib.PART_TRUNK) else None
+
+    def ptr(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        args = (B, P, k, ctypes.c_void_p(x.data_ptr()), params, _lib.SLOTS, BN_MOMENTUM,
-                ctypes.c_void_p(logp.data_ptr()), ctypes.c_void_p(trans.data_ptr()), None,
-                ctypes.c_void_p(ws.data_ptr()), ws.numel())
+        args = (B, P, k, ptr(x), params, _lib.SLOTS, BN_MOMENTUM, ptr(logp), ptr(trans), ptr(feat), ptr(ws), ws.numel())
         if conv3_ms is None:
-            _lib.check(lib.pngpd_train_forward(*args, stream))
+            _lib.check(lib.pngpd_train_forward_parts(parts, *args, stream))
         else:
             pair = (ctypes.c_float * 2)()
             _lib.check(lib.pngpd_train_forward_timed(*args, pair, stream))
             conv3_ms += [pair[0], pair[1]]
     _bump_num_batches(model)
     invalidate_packed_weights()        # running statistics changed under torch's version counters
-    return logp, trans, ws, x
+    if parts & _lib.PART_HEAD:
+        return logp, trans, ws, x
+    return logp, trans, ws, x, feat
 
 
 def critical_points(ws, B, P, k=2):
@@ -131,48 +145,71 @@ def saved_activation(ws, B, P, k, name):
 PARTS_ALL = _lib.PART_STN | _lib.PART_TRUNK | _lib.PART_HEAD
 
 
-def train_backward(model, x, logp, dlogp, dtrans, ws, grad_of, parts=PARTS_ALL):
+def train_backward(model, x, logp, dlogp, dtrans, ws, grad_of, parts=None, dfeat=None):
     """Backward of train_forward.  grad_of(param) -> tensor that receives that parameter's gradient.
-    `parts` (mask of _lib.PART_*) runs a segment only; segments must follow each other as HEAD, TRUNK, STN."""
+    `parts` (mask of _lib.PART_*, default: all the model owns) runs a segment only; segments must follow each other
+    as HEAD, TRUNK, STN.  dfeat: gradient w.r.t. the global feature of a model without a head."""
     lib = _lib.load()
     B, _, P = x.shape
-    k = model.fc3.out_features
+    k = _classes(model)
+    if parts is None:
+        parts = model._PARTS
     rows = _unit_tensors(model)
     params = _table(rows, lambda t, fi: t.data)
     grads = _table(rows, lambda t, fi: grad_of(t) if fi < 4 else None)
-    dlogp = dlogp.to(torch.float32).contiguous()
-    dtrans_p = None
-    if dtrans is not None:
-        dtrans = dtrans.to(torch.float32).contiguous()
-        dtrans_p = ctypes.c_void_p(dtrans.data_ptr())
+
+    def ptr(t):
+        return ctypes.c_void_p(t.to(torch.float32).contiguous().data_ptr()) if t is not None else None
+
+    keep = [t.to(torch.float32).contiguous() if t is not None else None for t in (dlogp, dtrans, dfeat)]
     with torch.cuda.device(x.device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(lib.pngpd_train_backward_part(B, P, k, ctypes.c_void_p(x.data_ptr()), params, grads, _lib.SLOTS,
-                                                 ctypes.c_void_p(logp.data_ptr()), ctypes.c_void_p(dlogp.data_ptr()),
-                                                 dtrans_p, ctypes.c_void_p(ws.data_ptr()), ws.numel(), parts, stream))
+                                                 ptr(logp), ptr(keep[0]), ptr(keep[1]), ptr(keep[2]),
+                                                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), parts, stream))
 
 
 class TrainFunction(torch.autograd.Function):
-    """autograd bridge: forward(model, x, *parameters) -> (logp, trans)."""
+    """autograd bridge: forward(model, x, *parameters) -> (logp, trans) for a PointNetCls, (feat, trans) for a
+    PointNetfeat, trans for an STN3d (model/pointnet.py:185-190, :135-149, :28-45 in train mode)."""
 
     @staticmethod
     def forward(ctx, model, x, *params):
-        logp, trans, ws, xc = train_forward(model, x)
+        out = train_forward(model, x)
+        logp, trans, ws, xc = out[:4]
         ctx.model, ctx.ws, ctx.x, ctx.logp, ctx.params = model, ws, xc, logp, params
-        return logp, trans
+        if model._PARTS & _lib.PART_HEAD:
+            return logp, trans
+        if model._PARTS & _lib.PART_TRUNK:
+            return out[4], trans
+        return trans
 
     @staticmethod
-    def backward(ctx, dlogp, dtrans):
+    def backward(ctx, *douts):
+        model = ctx.model
         grads = {id(p): torch.empty_like(p) for p in ctx.params}
-        if dlogp is None:
-            dlogp = torch.zeros_like(ctx.logp)
-        train_backward(ctx.model, ctx.x, ctx.logp, dlogp, dtrans, ctx.ws, lambda p: grads[id(p)])
+        grad_of = lambda p: grads[id(p)]        # noqa: E731
+        if model._PARTS & _lib.PART_HEAD:
+            dlogp, dtrans = douts
+            if dlogp is None:
+                dlogp = torch.zeros_like(ctx.logp)
+            train_backward(model, ctx.x, ctx.logp, dlogp, dtrans, ctx.ws, grad_of)
+        elif model._PARTS & _lib.PART_TRUNK:
+            dfeat, dtrans = douts
+            if dfeat is None:
+                dfeat = torch.zeros((ctx.x.shape[0], 1024), dtype=torch.float32, device=ctx.x.device)
+            train_backward(model, ctx.x, None, None, dtrans, ctx.ws, grad_of, dfeat=dfeat)
+        else:
+            (dtrans,) = douts
+            if dtrans is None:
+                dtrans = torch.zeros((ctx.x.shape[0], 3, 3), dtype=torch.float32, device=ctx.x.device)
+            train_backward(model, ctx.x, None, None, dtrans, ctx.ws, grad_of)
         ctx.ws = None
         return (None, None) + tuple(grads[id(p)] for p in ctx.params)
 
 
 def forward_train_mode(model, x):
-    """What PointNetCls.forward does in train() mode."""
+    """What PointNetCls / PointNetfeat / STN3d .forward do in train() mode."""
     params = [t for row in _unit_tensors(model) for t in row[:4] if t is not None]
     return TrainFunction.apply(model, x, *params)
 

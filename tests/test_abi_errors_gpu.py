@@ -119,7 +119,11 @@ def test_training_rejects_bad_calls():
     assert lib.pngpd_train_forward(B, P, k, vp(x), table, _lib.SLOTS, 0.1, vp(logp), None, None, vp(ws), 64, st) == ERR_WORKSPACE
     full = (ctypes.c_void_p * _lib.SLOTS)(*[x.data_ptr()] * _lib.SLOTS)
     for mask in (0, 8, 15):
-        assert lib.pngpd_train_backward_part(B, P, k, vp(x), full, full, _lib.SLOTS, vp(logp), vp(logp), None, vp(ws),
-                                             nbytes, mask, st) == ERR_INVALID and "part mask" in last_error(lib)
+        assert lib.pngpd_train_backward_part(B, P, k, vp(x), full, full, _lib.SLOTS, vp(logp), vp(logp), None, None,
+                                             vp(ws), nbytes, mask, st) == ERR_INVALID and "part mask" in last_error(lib)
+    assert lib.pngpd_train_backward_part(B, P, k, vp(x), full, full, _lib.SLOTS, vp(logp), vp(logp), None, vp(x), vp(ws),
+                                         nbytes, 7, st) == ERR_INVALID and "dfeat_dev" in last_error(lib)
+    assert lib.pngpd_train_forward_parts(2, B, P, k, vp(x), full, _lib.SLOTS, 0.1, vp(logp), None, None, vp(ws), nbytes,
+                                         st) == ERR_INVALID
     assert lib.pngpd_adam_step(vp(x), vp(x), vp(x), vp(x), 0, 0.1, 0.9, 0.999, 1e-8, 1, 1.0, st) == ERR_SHAPE
     assert lib.pngpd_nll_loss(vp(logp), None, B, k, vp(logp), vp(logp), st) == ERR_INVALID

@@ -314,11 +314,91 @@ def forced_forward(o, x, arg_stn, arg_trunk, masks):
     h = gate(stn.bn5(stn.fc2(h)), masks["stn_a2"])
     iden = torch.eye(3, dtype=x.dtype).reshape(1, 9)
     trans = (stn.fc3(h) + iden).reshape(-1, 3, 3)
+    forced_forward.trans, forced_forward.feat = trans, None
+    if arg_trunk is None:                               # the transform regressor alone
+        return None, kinks, pools
     xt = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
     pt = stack(o.feat, xt, "trunk", arg_trunk, False)
+    forced_forward.feat = pt
+    if "head_a1" not in masks:                          # a model without a head
+        return None, kinks, pools
     h = gate(o.bn1(o.fc1(pt)), masks["head_a1"])
     h = gate(o.bn2(o.fc2(h)), masks["head_a2"])
     return F.log_softmax(o.fc3(h), dim=1), kinks, pools
+
+
+@pytest.mark.parametrize("which", ["feat", "stn"])
+def test_standalone_submodules_in_train_mode(which):
+    """PointNetfeat and STN3d on their own in train() mode (model/pointnet.py:135-149, :28-45 with batch-statistics
+    BatchNorm), forward and backward through autograd, against a float64 step of the restated modules forced onto the
+    decisions the HIP forward took: outputs, every gradient, running statistics."""
+    from pointnetgpd_amd import training
+    from pointnetgpd_amd.pointnet import PointNetfeat, STN3d
+    P, B, seed, gain = 200, 12, 43, 1.3
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal"))
+    sd = synth.torch_state_dict(seed, 2, 1.0, gain)
+    g = torch.Generator().manual_seed(seed)
+    w_feat, w_trans = torch.randn(B, 1024, generator=g), torch.randn(B, 3, 3, generator=g)
+    if which == "feat":
+        m = PointNetfeat(P, 3)
+        m.load_state_dict({n[len("feat."):]: v for n, v in sd.items() if n.startswith("feat.")})
+        names = ("stn_h1", "stn_h2", "stn_pooled", "stn_a1", "stn_a2", "trunk_h1", "trunk_h2", "trunk_pooled")
+    else:
+        m = STN3d(P, 3)
+        m.load_state_dict({n[len("feat.stn."):]: v for n, v in sd.items() if n.startswith("feat.stn.")})
+        names = ("stn_h1", "stn_h2", "stn_pooled", "stn_a1", "stn_a2")
+    m = m.cuda().train()
+    # the autograd route a caller takes
+    if which == "feat":
+        feat, trans = m(x.cuda())
+        loss = (feat * w_feat.cuda()).sum() + (trans * w_trans.cuda()).sum()
+    else:
+        trans = m(x.cuda())
+        loss = (trans * w_trans.cuda()).sum()
+    loss.backward()
+    got = {n: p.grad.detach().cpu().double() for n, p in m.named_parameters()}
+    stats = {n: v.detach().cpu().clone() for n, v in m.state_dict().items()}
+    # the same forward again on a twin (identical state before the step) to read the decisions it took
+    twin = type(m)(P, 3)
+    cut = len("feat.") if which == "feat" else len("feat.stn.")
+    twin.load_state_dict({n[cut:]: v for n, v in sd.items() if n.startswith("feat." if which == "feat" else "feat.stn.")})
+    twin = twin.cuda().train()
+    out = training.train_forward(twin, x.cuda())
+    ws = out[2]
+    arg_stn, arg_trunk = (a.cpu() for a in training.critical_points(ws, B, P, 2))
+    masks = {n: (training.saved_activation(ws, B, P, 2, n) > 0).cpu() for n in names}
+    o = po.build_cls(P, 2, sd, eval_mode=False).double()
+    _, kinks, pools = forced_forward(o, x.double(), arg_stn, arg_trunk if which == "feat" else None, masks)
+    for chosen, true_max in pools:
+        assert float((true_max - chosen).detach().max()) < 2e-6 * float(true_max.detach().abs().max())
+    for pre, mask in kinks:
+        wrong = (pre.detach() > 0) != mask
+        if wrong.any():
+            assert float(pre.detach()[wrong].abs().max()) < 2e-5 * float(pre.detach().abs().max())
+    ref_trans = forced_forward.trans
+    np.testing.assert_allclose(trans.detach().cpu().numpy(), ref_trans.detach().numpy(), atol=1e-4)
+    ref_loss = (ref_trans * w_trans.double()).sum()
+    if which == "feat":
+        np.testing.assert_allclose(feat.detach().cpu().numpy(), forced_forward.feat.detach().numpy(), rtol=2e-5, atol=1e-4)
+        ref_loss = ref_loss + (forced_forward.feat * w_feat.double()).sum()
+    ref_loss.backward()
+    prefix = "feat." if which == "feat" else "feat.stn."
+    checked = 0
+    for n, gh in got.items():
+        r = o.get_parameter(prefix + n).grad
+        scale = float(r.abs().max())
+        if scale < 1e-7 * max(1.0, float(w_trans.abs().max())):
+            assert float(gh.abs().max()) < 1e-4, n
+            continue
+        assert float((gh - r).abs().max()) / scale < 1e-4, (n, float((gh - r).abs().max()) / scale)
+        checked += 1
+    assert checked >= (16 if which == "feat" else 10)
+    ref_sd = o.state_dict()
+    for n, v in stats.items():
+        if n.endswith(("running_mean", "running_var")):
+            np.testing.assert_allclose(v.numpy(), ref_sd[prefix + n].numpy(), rtol=2e-4, atol=2e-5, err_msg=n)
+        elif n.endswith("num_batches_tracked"):
+            assert int(v) == 1
 
 
 @pytest.mark.parametrize("P,B,k,seed", [(130, 70, 2, 8), (64, 70, 2, 8), (64, 70, 2, 13), (37, 150, 2, 9),
