@@ -265,6 +265,19 @@ int pngpd_model_load(pngpd_model* m, const float* const* host_tensors, int n_slo
     HIP_TRY(hipGetDevice(&dev));
     if (dev != m->device)
         return fail(PNGPD_ERR_STATE, "model lives on device %d but device %d is current", m->device, dev);
+    // validate the whole table before the first upload: a table that fails half-way must not leave the model with
+    // one part new and one part old
+    for (int u = 0; u < PNGPD_UNITS; ++u) {
+        const bool owned = u <= PNGPD_U_STN_FC3 ? (m->parts & PNGPD_PART_STN)
+                           : u <= PNGPD_U_FEAT_CONV3 ? (m->parts & PNGPD_PART_TRUNK) : (m->parts & PNGPD_PART_HEAD);
+        if (!owned) continue;
+        const float* const* f = host_tensors + u * PNGPD_FIELDS;
+        const bool has_bn = (u != PNGPD_U_STN_FC3 && u != PNGPD_U_FC3);
+        if (!f[PNGPD_F_WEIGHT] || !f[PNGPD_F_BIAS])
+            return fail(PNGPD_ERR_INVALID, "weight table: unit %d has no weight/bias", u);
+        if (has_bn && (!f[PNGPD_F_BN_WEIGHT] || !f[PNGPD_F_BN_BIAS] || !f[PNGPD_F_BN_MEAN] || !f[PNGPD_F_BN_VAR]))
+            return fail(PNGPD_ERR_INVALID, "weight table: unit %d lacks BatchNorm tensors", u);
+    }
     m->loaded = false;
     std::vector<PackedStack> keep_stacks;
     keep_stacks.reserve(2);
@@ -272,6 +285,12 @@ int pngpd_model_load(pngpd_model* m, const float* const* host_tensors, int n_slo
     keep_fc.reserve(12);
     std::vector<std::vector<uint16_t>> keep16;
     keep16.reserve(4);
+    // The uploads below are asynchronous copies out of the staging vectors above.  Declared after them, this guard
+    // is destroyed first: whichever way the function is left, the stream has drained before a vector is freed.
+    struct DrainOnExit {
+        hipStream_t s;
+        ~DrainOnExit() { (void)hipStreamSynchronize(s); }
+    } drain{s};
     int rc;
     if (m->parts & PNGPD_PART_STN) {
         if ((rc = load_stack(host_tensors, PNGPD_U_STN_CONV1, m->stn, keep_stacks, s))) return rc;

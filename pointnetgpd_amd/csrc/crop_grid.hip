@@ -124,13 +124,14 @@ __device__ __forceinline__ unsigned part_bits4(unsigned v) {          // abcd ->
     return v;
 }
 
-__device__ __forceinline__ int grasp_bin(const double* __restrict__ f, const CropLimits& L,
-                                         const GridParams* __restrict__ gp) {
-    const double mx = 0.5 * (L.xlo + L.xhi), my = 0.5 * (L.ylo + L.yhi), mz = 0.5 * (L.zlo + L.zhi);
+// scale[c] = 16 coarse cells per axis over the grid's extent, prepared once per thread (binning_scale)
+__device__ __forceinline__ int grasp_bin(const double* __restrict__ f, const double* mid, const double* origin,
+                                         const double* scale) {
     unsigned code = 0;
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double w = f[c] + mx * f[3 + c] + my * f[6 + c] + mz * f[9 + c];      // box centre (unit rows assumed)
-        double t = (w - gp->origin[c]) * gp->inv_cell * 16.0 / (double)gp->dim[c];
+        const double w = f[c] + mid[0] * f[3 + c] + mid[1] * f[6 + c] + mid[2] * f[9 + c];      // box centre (unit rows assumed)
+        double t = (w - origin[c]) * scale[c];
         t = t >= 0.0 ? t : 0.0;                                                     // NaN lands in bin 0
         const unsigned q = t < 15.0 ? (unsigned)t : 15u;
         code |= part_bits4(q) << c;
@@ -138,13 +139,38 @@ __device__ __forceinline__ int grasp_bin(const double* __restrict__ f, const Cro
     return (int)code;
 }
 
+constexpr int ORDER_CACHE = 16384;      // grasps whose bin is kept in LDS between the two passes
+
 __device__ __forceinline__ void grasp_order(const double* __restrict__ frames, int G, const CropLimits& L,
                                             const GridParams* __restrict__ gp, int* __restrict__ perm, int* s_bin,
-                                            int* s_wave) {
+                                            int* s_wave, unsigned short* s_key) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double mid[3] = {0.5 * (L.xlo + L.xhi), 0.5 * (L.ylo + L.yhi), 0.5 * (L.zlo + L.zhi)};
+    double origin[3], scale[3];
+    for (int c = 0; c < 3; ++c) {
+        origin[c] = gp->origin[c];
+        scale[c] = gp->inv_cell * 16.0 / (double)gp->dim[c];
+    }
     for (int i = tid; i < ORDER_BINS; i += 1024) s_bin[i] = 0;
     __syncthreads();
-    for (int g = tid; g < G; g += 1024) atomicAdd(&s_bin[grasp_bin(frames + (size_t)g * 12, L, gp)], 1);
+    // pass 1: bin of every grasp (kept for pass 2 while it fits), four grasps per thread and step so that their
+    // frame loads overlap
+    for (int g0 = tid; g0 < G; g0 += 4096) {
+        int key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + 1024 * u;
+            key[u] = g < G ? grasp_bin(frames + (size_t)g * 12, mid, origin, scale) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + 1024 * u;
+            if (key[u] >= 0) {
+                atomicAdd(&s_bin[key[u]], 1);
+                if (g < ORDER_CACHE) s_key[g] = (unsigned short)key[u];
+            }
+        }
+    }
     __syncthreads();
     const int c0 = s_bin[4 * tid], c1 = s_bin[4 * tid + 1], c2 = s_bin[4 * tid + 2], c3 = s_bin[4 * tid + 3];
     const int sum = c0 + c1 + c2 + c3;
@@ -163,8 +189,10 @@ __device__ __forceinline__ void grasp_order(const double* __restrict__ frames, i
     s_bin[4 * tid + 2] = run + c0 + c1;
     s_bin[4 * tid + 3] = run + c0 + c1 + c2;
     __syncthreads();
-    for (int g = tid; g < G; g += 1024)
-        perm[atomicAdd(&s_bin[grasp_bin(frames + (size_t)g * 12, L, gp)], 1)] = g;
+    for (int g = tid; g < G; g += 1024) {
+        const int key = g < ORDER_CACHE ? (int)s_key[g] : grasp_bin(frames + (size_t)g * 12, mid, origin, scale);
+        perm[atomicAdd(&s_bin[key], 1)] = g;
+    }
 }
 
 // Position in perm[] that workgroup `b` of `n` takes: workgroups are handed to the 8 XCDs in turn, so the
@@ -183,7 +211,8 @@ __global__ __launch_bounds__(1024) void k_scan_cells(const GridParams* __restric
     __shared__ int s_wave[16];
     if (blockIdx.x == 1) {                              // launched only when an order is wanted
         __shared__ int s_bin[ORDER_BINS];
-        grasp_order(frames, G, L, gp, perm, s_bin, s_wave);
+        __shared__ unsigned short s_key[ORDER_CACHE];
+        grasp_order(frames, G, L, gp, perm, s_bin, s_wave, s_key);
         return;
     }
     const int ncells = gp->dim[0] * gp->dim[1] * gp->dim[2];
@@ -337,6 +366,19 @@ __device__ __forceinline__ bool row_range_serial(const double* __restrict__ f, c
     p0 = start[cb + first];
     p1 = start[cb + last + 1];
     return p0 < p1;
+}
+
+// Point ranges of up to 256 rows of cells (rows row0 .. of the grasp's cell box), one row per thread, into
+// row_p0 / row_p1 (empty rows get p0 == p1).  The caller places barriers around it.
+__device__ __forceinline__ void fill_row_table(const double* __restrict__ f, const CropLimits& L, const GraspCells& gc,
+                                               const GridParams* __restrict__ gp, const int* __restrict__ start, int ny,
+                                               int nrows, int row0, int tid, int* row_p0, int* row_p1) {
+    const int row = row0 + tid;
+    int p0 = 0, p1 = 0;
+    if (row < nrows && !row_range_serial(f, L, gc, gp, start, gc.c0[1] + row % ny, gc.c0[2] + row / ny, p0, p1))
+        p0 = p1 = 0;
+    row_p0[tid] = p0;
+    row_p1[tid] = p1;
 }
 
 // cnt[g] = points inside the gripper region
@@ -509,28 +551,33 @@ __global__ __launch_bounds__(256) void k_cull_emit(const float* __restrict__ sce
         }
     };
     const unsigned long long below = (1ull << lane) - 1ull;
+    int* row_p0 = s_small;                       // [256] point range of a row of cells; free again before the sort
+    int* row_p1 = s_small + 256;
     if (n <= CULL_CAP) {
         if (tid == 0) s_fill = 0;
-        __syncthreads();
-        for (int row = wave; row < nrows; row += 4) {
-            const int iy = gc.c0[1] + row % ny, iz = gc.c0[2] + row / ny;
-            int p0, p1;
-            if (!row_range(f, L, gc, gp, start, iy, iz, lane, p0, p1)) continue;
-            for (int p = p0; p < p1; p += 64) {           // wave-uniform trip count: ballots stay whole
-                bool hit = false;
-                int s = 0;
-                if (p + lane < p1) {
-                    const float4 v = sorted[p + lane];
-                    hit = in_box(to_gripper(f, (double)v.x, (double)v.y, (double)v.z), L);
-                    s = __float_as_int(v.w);
+        for (int row0 = 0; row0 < nrows; row0 += 256) {    // one thread per row of cells finds its point range
+            __syncthreads();
+            fill_row_table(f, L, gc, gp, start, ny, nrows, row0, tid, row_p0, row_p1);
+            __syncthreads();
+            const int nt = min(256, nrows - row0);
+            for (int row = wave; row < nt; row += 4) {
+                const int p0 = row_p0[row], p1 = row_p1[row];
+                for (int p = p0; p < p1; p += 64) {       // wave-uniform trip count: ballots stay whole
+                    bool hit = false;
+                    int s = 0;
+                    if (p + lane < p1) {
+                        const float4 v = sorted[p + lane];
+                        hit = in_box(to_gripper(f, (double)v.x, (double)v.y, (double)v.z), L);
+                        s = __float_as_int(v.w);
+                    }
+                    const unsigned long long bal = __ballot(hit);
+                    if (bal == 0ull) continue;
+                    int at = 0;
+                    if (lane == 0) at = atomicAdd(&s_fill, __popcll(bal));
+                    at = __shfl(at, 0);
+                    const int pos = at + (int)__popcll(bal & below);
+                    if (hit && pos < CULL_CAP) list[pos] = s;  // pos < n <= CULL_CAP when cnt is this scene's count
                 }
-                const unsigned long long bal = __ballot(hit);
-                if (bal == 0ull) continue;
-                int at = 0;
-                if (lane == 0) at = atomicAdd(&s_fill, __popcll(bal));
-                at = __shfl(at, 0);
-                const int pos = at + (int)__popcll(bal & below);
-                if (hit && pos < CULL_CAP) list[pos] = s;      // pos < n <= CULL_CAP when cnt is this scene's count
             }
         }
         __syncthreads();
@@ -547,18 +594,21 @@ __global__ __launch_bounds__(256) void k_cull_emit(const float* __restrict__ sce
     for (int lo = 0; lo < S; lo += 32 * CULL_CAP) {
         for (int w = tid; w < CULL_CAP; w += 256) list[w] = 0;
         __syncthreads();
-        for (int row = wave; row < nrows; row += 4) {
-            const int iy = gc.c0[1] + row % ny, iz = gc.c0[2] + row / ny;
-            int p0, p1;
-            if (!row_range(f, L, gc, gp, start, iy, iz, lane, p0, p1)) continue;
-            for (int p = p0 + lane; p < p1; p += 64) {
-                const float4 v = sorted[p];
-                const int s = __float_as_int(v.w) - lo;
-                if (s >= 0 && s < 32 * CULL_CAP && in_box(to_gripper(f, (double)v.x, (double)v.y, (double)v.z), L))
-                    atomicOr((unsigned int*)&list[s >> 5], 1u << (s & 31));
+        for (int row0 = 0; row0 < nrows; row0 += 256) {
+            fill_row_table(f, L, gc, gp, start, ny, nrows, row0, tid, row_p0, row_p1);
+            __syncthreads();
+            const int nt = min(256, nrows - row0);
+            for (int row = wave; row < nt; row += 4) {
+                const int p0 = row_p0[row], p1 = row_p1[row];
+                for (int p = p0 + lane; p < p1; p += 64) {
+                    const float4 v = sorted[p];
+                    const int s = __float_as_int(v.w) - lo;
+                    if (s >= 0 && s < 32 * CULL_CAP && in_box(to_gripper(f, (double)v.x, (double)v.y, (double)v.z), L))
+                        atomicOr((unsigned int*)&list[s >> 5], 1u << (s & 31));
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
         for (int w0 = 0; w0 < CULL_CAP; w0 += 256) {
             unsigned int word = (unsigned int)list[w0 + tid];
             const int mine = __popc(word);
@@ -638,14 +688,7 @@ __global__ __launch_bounds__(256) void k_cull_gather(const float* __restrict__ s
     int* row_p1 = s_small + 256;
     for (int row0 = 0; row0 < nrows; row0 += 256) {
         __syncthreads();                               // s_fill is set; the previous tile's table has been read
-        {
-            const int row = row0 + tid;
-            int p0 = 0, p1 = 0;
-            if (row < nrows && !row_range_serial(f, L, gc, gp, start, gc.c0[1] + row % ny, gc.c0[2] + row / ny, p0, p1))
-                p0 = p1 = 0;
-            row_p0[tid] = p0;
-            row_p1[tid] = p1;
-        }
+        fill_row_table(f, L, gc, gp, start, ny, nrows, row0, tid, row_p0, row_p1);
         __syncthreads();
         const int nt = min(256, nrows - row0);
         for (int row = wave; row < nt; row += 4) {
