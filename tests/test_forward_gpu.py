@@ -234,3 +234,29 @@ def test_p1000_full_view_variant():
         m.precision = precision
         logp, _ = m(x.cuda())
         assert (logp.cpu() - ref).abs().max().item() <= tol
+
+
+def test_bf16_error_against_logit_magnitude():
+    """The 2e-2 absolute bar of the bf16 path is met on networks whose class scores differ by a few units; the error
+    itself is proportional to the scores (bf16 rounds h1, h2 and the weights to 2^-9 relative).  Networks of growing
+    weight gain show it: the error stays below 1 % of the largest score difference at every gain, the absolute bar
+    fails beyond a score difference of about 5, and the exact-f32 mode holds its 1e-4 relative to the same scale."""
+    P, k, seed, B = 750, 2, 47, 64
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, "gripper"))
+    rows = []
+    for gain in (1.5, 2.0, 2.5, 3.0, 3.5):
+        sd = synth.torch_state_dict(seed, k, 0.02, gain)
+        with torch.no_grad():
+            ref = po.build_cls(P, k, sd)(x)[0].double()
+        spread = (ref.max(1).values - ref.min(1).values).max().item()       # = largest |logit_0 - logit_1|
+        errs = {}
+        for precision in ("bf16", "fp32"):
+            logp = hip_model(P, k, seed, 0.02, precision, gain)(x.cuda())[0].cpu().double()
+            errs[precision] = (logp - ref).abs().max().item()
+        rows.append((gain, spread, errs["bf16"], errs["fp32"]))
+        print(f"gain {gain}: largest score difference {spread:8.3f}  bf16 err {errs['bf16']:.3e} "
+              f"({100 * errs['bf16'] / max(spread, 1.0):.2f} %)  fp32 err {errs['fp32']:.3e}")
+    for gain, spread, e16, e32 in rows:
+        assert e16 <= 0.01 * max(spread, 2.0), (gain, spread, e16)
+        assert e32 <= 1e-4 * max(1.0, spread / 5.0), (gain, spread, e32)
+    assert rows[-1][1] > 5.0            # the sweep does reach scores where the absolute bar no longer applies
