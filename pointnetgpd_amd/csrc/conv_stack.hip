@@ -8,8 +8,9 @@
 // exists: a tile of points goes from its input coordinates to a per-channel maximum on chip.
 //
 // Common to both precisions:
-//   * layer 1 (K = 3) runs on the VALU, straight into the MFMA B-operand layout of layer 2, with
-//     the candidate's 3x3 input transform folded into the 64x3 weight table;
+//   * layer 1 (K = 3) lands straight in the MFMA B-operand layout of layer 2, with the candidate's 3x3 input
+//     transform folded into the 64x3 weight table (f32 path: on the VALU; bf16 path: on the matrix pipe at float32
+//     accuracy, see produce_tiles);
 //   * layer 2 is computed TRANSPOSED, X[ch2][point] = W2-fragments * h1-fragments, so that the
 //     accumulator (point on the lane, channels in the registers) is, after ReLU, directly the A
 //     operand of layer 3: no transposition through LDS, no cross-lane traffic.  The k order this
@@ -127,7 +128,7 @@ __device__ __forceinline__ void write_pooled(const ConvStackArgs& a, int b, cons
 // higher clock on it under sustained load (same cycles per flop, ~12 % more flop/s).
 //
 // LDS: [0,128K) two batches of A fragments | [128K,144K) W2 fragments | conv2 bias |
-//      per-wave conv1 tables (trans folded in; private to a wave, so no workgroup barrier) | conv3 bias.
+//      BN-folded conv1 table | two candidates' layer-1 A fragments (trans folded in) | conv3 bias.
 // ------------------------------------------------------------------------------------------
 constexpr int WS_WAVES = 8;
 constexpr int WS_THREADS = WS_WAVES * 64;
@@ -149,8 +150,8 @@ constexpr int WS_BATCH_BYTES = W16_BATCH_TILES * W16_TILE_BYTES;
 constexpr int WS_OFF_W2 = 2 * WS_BATCH_BYTES;
 constexpr int WS_OFF_B2 = WS_OFF_W2 + (int)W2P_BF16_BYTES;
 constexpr int WS_OFF_W1B = WS_OFF_B2 + C2 * 4;             // BN-folded conv1 table, shared
-constexpr int WS_OFF_W1 = WS_OFF_W1B + C1 * 16;            // per-wave copies with trans folded in
-constexpr int WS_OFF_B3 = WS_OFF_W1 + WS_WAVES * C1 * 16;   // conv3 bias: read once per candidate by every wave
+constexpr int WS_OFF_W1 = WS_OFF_W1B + C1 * 16;            // layer-1 A fragments of two candidates (2 x W1F_BYTES)
+constexpr int WS_OFF_B3 = WS_OFF_W1 + 2 * 4096;            // conv3 bias: read once per candidate by every wave
 constexpr int WS_LDS_BYTES = WS_OFF_B3 + C3 * 4;
 typedef f32x4 f32x4v;
 
@@ -185,24 +186,54 @@ __device__ __forceinline__ bf16x8 relu_pack(const f32x4v& lo, const f32x4v& hi) 
     return __builtin_bit_cast(bf16x8, r);
 }
 
-// Coordinates of the two tiles of 16 points a wave produces; lane (c, q) holds point c of each.
+// Layer 1 (3 -> 64, K = 3 plus the bias) also runs on the matrix pipe, as ONE v_mfma_f32_16x16x32_bf16 per tile of
+// 16 channels x 16 points, at float32 accuracy: every float is cut into three bf16 pieces by truncation,
+// v = vh + vm + vl exactly (3 x 8 significand bits), and the 32 k slots of the instruction hold, for each of the
+// three coordinates, the six piece products xh*wh, xh*wm, xm*wh, xh*wl, xm*wm, xl*wh (what is left out is below
+// 2^-23 of the product), plus the bias pieces against 1.0:
+//
+//     k slot      0   1   2   3   4   5   6   7  | 8..13   14  15 | 16..21  22 23 | 24..31
+//     B (points)  xh  xh  xm  xh  xm  xl  1   1  | same for y  1   0 | same for z 0  0 |  0
+//     A (weights) wh  wm  wh  wl  wm  wh  bh  bm | same for y  bl  0 | same for z 0  0 |  0
+//
+// so lane (c, q) of the B operand needs nothing but coordinate q of point c (q = 3: zeros).  On the VALU this
+// layer was 48 packed fmas and 16 LDS reads per produce step (of two tiles); here it is 14 VALU instructions,
+// 4 LDS reads and 8 MFMAs, and the step - during which the other wave of the SIMD has the matrix pipe to itself and
+// cannot fill it - is shorter: +1.9 % candidates/s in a one-box A/B.
+// The rows of an A tile are a permutation of the channels chosen so that the accumulators of tiles (s, 0) and
+// (s, 1) are, after ReLU and packing, lane (c, q)'s eight k slots 32s + 8q .. + 7 of layer 2's B operand.
+constexpr int W1F_BYTES = 4 * 64 * 16;            // [tile 2s+hl][q][row] x 16 B: the A fragments of one candidate
+static_assert(WS_OFF_B3 - WS_OFF_W1 == 2 * W1F_BYTES, "LDS room for two layer-1 tables");
+
+__device__ __forceinline__ unsigned int f2u(float v) { return __builtin_bit_cast(unsigned int, v); }
+__device__ __forceinline__ float u2f(unsigned int v) { return __builtin_bit_cast(float, v); }
+
+// bf16 bit patterns (upper halves) of the three pieces of v
+__device__ __forceinline__ void split3(float v, unsigned int& h, unsigned int& m, unsigned int& l) {
+    h = f2u(v) & 0xffff0000u;
+    const float r1 = v - u2f(h);
+    m = f2u(r1) & 0xffff0000u;
+    l = f2u(r1 - u2f(m));                      // at most 8 significant bits are left: exact as bf16
+}
+
+// Coordinate q of point c of the two tiles a wave produces next (lanes with q = 3 hold 0).
 struct TilePoints {
-    float x0[2], x1[2], x2[2];
+    float x[2];
 };
 
-__device__ __forceinline__ void load_tile_points(const ConvStackArgs& a, int b, int tile0, int c, TilePoints& p) {
+__device__ __forceinline__ void load_tile_points(const ConvStackArgs& a, int b, int tile0, int c, int q, TilePoints& p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         int pt = (tile0 + u) * 16 + c;
         pt = pt < a.P ? pt : a.P - 1;
-        load_point(a, b, pt, p.x0[u], p.x1[u], p.x2[u]);
+        const size_t at = a.layout == PNGPD_LAYOUT_C3P ? ((size_t)b * 3 + q) * a.P + pt : ((size_t)b * a.P + pt) * 3 + q;
+        p.x[u] = q < 3 ? a.x[at] : 0.f;
     }
 }
 
-// The wave's private conv1 table for candidate b (model/pointnet.py:138-142: the 3x3 input
-// transform is applied to the points before conv1; here it is applied to conv1's weights).
-__device__ __forceinline__ void fold_table(const ConvStackArgs& a, int b, const float4* s_w1base, float4* s_w1w,
-                                           int lane) {
+// The layer-1 A fragments of candidate b (model/pointnet.py:138-142: the 3x3 input transform is applied to the
+// points before conv1; here it is applied to conv1's weights).  One wave; lane = channel.
+__device__ __forceinline__ void fold_w1_frags(const ConvStackArgs& a, int b, const float4* s_w1base, char* tab, int lane) {
     float4 w = s_w1base[lane];
     if (a.trans != nullptr) {
         const float* T = a.trans + (size_t)b * 9;
@@ -213,9 +244,22 @@ __device__ __forceinline__ void fold_table(const ConvStackArgs& a, int b, const 
         f.w = w.w;
         w = f;
     }
-    wave_lds_sync();
-    s_w1w[lane] = w;
-    wave_lds_sync();
+    // channel 32s + 8q' + 4hl + i is row 4q' + i of tile 2s + hl
+    const int t = 2 * (lane >> 5) + ((lane >> 2) & 1), r = 4 * ((lane & 31) >> 3) + (lane & 3);
+    unsigned int bh, bm, bl;
+    split3(w.w, bh, bm, bl);
+    const float comp[3] = {w.x, w.y, w.z};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        unsigned int h, m, l;
+        split3(comp[d], h, m, l);
+        u32x4 v;
+        v[0] = (h >> 16) | m;                  // slots 0, 1: wh, wm
+        v[1] = (h >> 16) | l;                  //       2, 3: wh, wl
+        v[2] = (m >> 16) | h;                  //       4, 5: wm, wh
+        v[3] = d == 0 ? ((bh >> 16) | bm) : d == 1 ? (bl >> 16) : 0u;
+        *(u32x4*)(tab + ((t * 4 + d) * 16 + r) * 16) = v;
+    }
 }
 
 // Layers 1-2 of two tiles of 16 points; their layer-3 A fragments go to dst, dst + 4 KiB.
@@ -238,38 +282,42 @@ __device__ __forceinline__ void load_l2frags(L2Frags& f, int ks, const char* s_w
     }
 }
 
-__device__ __forceinline__ void produce_tiles(const TilePoints& p, const float4* s_w1w, const char* s_w2,
+__device__ __forceinline__ void produce_tiles(const TilePoints& p, const char* s_w1f, unsigned int ones, const char* s_w2,
                                               const float* s_b2, char* dst, int lane) {
-    const int q = lane >> 4;
     bf16x8 hb[2][2];
-    // the two tiles ride in the two halves of packed-f32 instructions
-    const f32x2 X0 = {p.x0[0], p.x0[1]}, X1 = {p.x1[0], p.x1[1]}, X2 = {p.x2[0], p.x2[1]};
+    bf16x8 xb[2];
+    // every LDS read of layer 1 and the first k-step of layer 2 is issued before anything waits for one
+    bf16x8 w1f[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        u32x4 r[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {          // 4 table rows per group of LDS reads
-            float4 w[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = s_w1w[32 * s + 8 * q + 4 * g + j];
-            __builtin_amdgcn_sched_barrier(0);
-            f32x2 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x2 wx = {w[j].x, w[j].x}, wy = {w[j].y, w[j].y}, wz = {w[j].z, w[j].z}, wb = {w[j].w, w[j].w};
-                v[j] = __builtin_elementwise_fma(wx, X0, __builtin_elementwise_fma(wy, X1, __builtin_elementwise_fma(wz, X2, wb)));
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                r[u][2 * g] = relu_pack2(v[0][u], v[1][u]);
-                r[u][2 * g + 1] = relu_pack2(v[2][u], v[3][u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) hb[u][s] = __builtin_bit_cast(bf16x8, r[u]);
-    }
+    for (int t = 0; t < 4; ++t) w1f[t] = *(const bf16x8*)(s_w1f + (t * 64 + lane) * 16);
     L2Frags fa, fb;
     load_l2frags(fa, 0, s_w2, s_b2, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const unsigned int x = f2u(p.x[u]);
+        const float r1 = p.x[u] - u2f(x & 0xffff0000u);
+        const unsigned int m = f2u(r1);
+        const unsigned int l = f2u(r1 - u2f(m & 0xffff0000u));
+        u32x4 v;
+        v[0] = __builtin_amdgcn_perm(x, x, 0x03020302u);      // xh, xh
+        v[1] = __builtin_amdgcn_perm(x, m, 0x07060302u);      // xm, xh
+        v[2] = __builtin_amdgcn_perm(l, m, 0x07060302u);      // xm, xl
+        v[3] = ones;
+        xb[u] = __builtin_bit_cast(bf16x8, v);
+    }
+    const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        f32x4v h1[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            h1[u][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[2 * s], xb[u], zero, 0, 0, 0);
+            h1[u][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[2 * s + 1], xb[u], zero, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) hb[u][s] = relu_pack(h1[u][0], h1[u][1]);
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         L2Frags& cur = (ks & 1) ? fb : fa;
@@ -366,7 +414,9 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
     char* s_w2 = smem + WS_OFF_W2;
     float* s_b2 = (float*)(smem + WS_OFF_B2);
     float4* s_w1base = (float4*)(smem + WS_OFF_W1B);
-    float4* s_w1w = (float4*)(smem + WS_OFF_W1) + wave * C1;
+    char* s_w1f = smem + WS_OFF_W1;               // layer-1 A fragments: two candidates' tables of W1F_BYTES
+    // slots 6, 7 of this lane's eight layer-1 k slots: the ones that meet the bias pieces
+    const unsigned int ones = q == 0 ? 0x3f803f80u : q == 1 ? 0x00003f80u : 0u;
 
     const int ct0 = (piece_of<NT>() * WS_WAVES + wave) * NT;      // first channel tile of this wave
     bf16x8 bw[NT][4];
@@ -384,6 +434,8 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
     if (tid < C1) s_w1base[tid] = a.w1tab[tid];
     float* s_b3 = (float*)(smem + WS_OFF_B3);
     for (int i = tid; i < C3; i += WS_THREADS) s_b3[i] = a.b3[i];
+    if (tid < 2 * 4 * 16)                          // k slots 24..31 of both tables stay zero for the whole kernel
+        *(u32x4*)(s_w1f + (tid >> 6) * W1F_BYTES + ((((tid >> 4) & 3) * 4 + 3) * 16 + (tid & 15)) * 16) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
 
     const int ntiles = (a.P + 15) >> 4;
@@ -391,32 +443,32 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
     const int stride = gridDim.x;
     const int ncand = (a.B - (int)blockIdx.x + stride - 1) / stride;
 
-    // Produce cursor: the (candidate, batch, half) this wave produces next.  Its points are
-    // loaded one step ahead and its conv1 table is folded when the candidate changes, so
-    // neither latency sits in front of a produce step.
-    const bool producer = wave < PRODUCER_WAVES;
-    int pb = blockIdx.x, pbt = 0, phalf = 0;
-    const int first_tile = 2 * PRODUCE_STEPS * wave;       // of this wave, within a batch
-    bool ptile = producer && first_tile < ntiles;
+    // Produce cursor: the (candidate, batch, half) this wave produces next; every wave's cursor moves to the next
+    // candidate in the same batch.  The points are loaded one step ahead.  The layer-1 table of a candidate is
+    // written by wave 0 when its cursor reaches that candidate, into the table the previous candidate does not
+    // use; the first produce step that reads it lies behind the barrier that ends the batch, and the table it
+    // replaces was last read a batch earlier.
+    static_assert(PRODUCE_STEPS == 1 && PRODUCER_WAVES == WS_WAVES, "one produce step per wave and batch");
+    int pb = blockIdx.x, pbt = 0, ptab = 0;
+    const int first_tile = 2 * wave;                       // of this wave, within a batch
+    bool ptile = first_tile < ntiles;
     TilePoints px;
-    if (producer) fold_table(a, pb, s_w1base, s_w1w, lane);
-    if (ptile) load_tile_points(a, pb, first_tile, c, px);
+    if (wave == 0) fold_w1_frags(a, pb, s_w1base, s_w1f, lane);
+    if (ptile) load_tile_points(a, pb, first_tile, c, q, px);
+    __syncthreads();
     auto produce_step = [&](char* batch_base) {
-        if (ptile) produce_tiles(px, s_w1w, s_w2, s_b2, batch_base + (first_tile + 2 * phalf) * W16_TILE_BYTES, lane);
-        if (++phalf == PRODUCE_STEPS) {
-            phalf = 0;
-            if (++pbt == nbatch) {
-                pbt = 0;
-                pb += stride;
-                if (pb < a.B) fold_table(a, pb, s_w1base, s_w1w, lane);
-            }
+        if (ptile) produce_tiles(px, s_w1f + ptab * W1F_BYTES, ones, s_w2, s_b2, batch_base + first_tile * W16_TILE_BYTES, lane);
+        if (++pbt == nbatch) {
+            pbt = 0;
+            pb += stride;
+            ptab ^= 1;
+            if (wave == 0 && pb < a.B) fold_w1_frags(a, pb, s_w1base, s_w1f + ptab * W1F_BYTES, lane);
         }
-        const int tile0 = pbt * W16_BATCH_TILES + first_tile + 2 * phalf;
+        const int tile0 = pbt * W16_BATCH_TILES + first_tile;
         ptile = pb < a.B && tile0 < ntiles;
-        if (ptile) load_tile_points(a, pb, tile0, c, px);
+        if (ptile) load_tile_points(a, pb, tile0, c, q, px);
     };
-    if (producer)
-        for (int st = 0; st < PRODUCE_STEPS; ++st) produce_step(s_a);
+    produce_step(s_a);
     __syncthreads();
 
 #ifdef PNGPD_STAMPS
@@ -435,9 +487,8 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
         for (int bt = 0; bt < nbatch; ++bt, buf ^= 1) {
             const int nt_b = min(W16_BATCH_TILES, ntiles - W16_BATCH_TILES * bt);
             const int npairs = (nt_b + 1) >> 1;
-            // pair indices in front of which this wave's two produce steps sit
-            const int step0 = producer ? min(wave, npairs - 1) : -1;
-            const int step1 = producer && PRODUCE_STEPS > 1 ? min(wave + PRODUCER_WAVES, npairs - 1) : -1;
+            // pair index in front of which this wave's produce step sits
+            const int step0 = min(wave, npairs - 1);
             const char* cur = s_a + buf * WS_BATCH_BYTES;
             char* nxt = s_a + (buf ^ 1) * WS_BATCH_BYTES;
             STAMP(g, 0);
@@ -448,12 +499,11 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
             load_afrags(afA, cur, lane);
             f32x4v carry = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             for (int i = 0; i < (nt_b >> 1); ++i) {
-                if (i == step0 || i == step1) {
+                if (i == step0) {
                     STAMP(g, 1);
                     __builtin_amdgcn_s_setprio(PNGPD_PRIO_PRODUCE);
 #ifndef PNGPD_ABLATE_PRODUCE
-                    if (i == step0) produce_step(nxt);
-                    if (i == step1) produce_step(nxt);
+                    produce_step(nxt);
 #endif
                     __builtin_amdgcn_s_setprio(PNGPD_PRIO_CONSUME);
                     STAMP(g, 2);
@@ -470,10 +520,9 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
             }
             if (nt_b & 1) {                       // odd tail: afA already holds tile nt_b-1
                 const int i = nt_b >> 1;
-                if (i == step0 || i == step1) {
+                if (i == step0) {
                     __builtin_amdgcn_s_setprio(PNGPD_PRIO_PRODUCE);
-                    if (i == step0) produce_step(nxt);
-                    if (i == step1) produce_step(nxt);
+                    produce_step(nxt);
                     __builtin_amdgcn_s_setprio(PNGPD_PRIO_CONSUME);
                 }
                 consume_tile(afA, bw, carry, rm);

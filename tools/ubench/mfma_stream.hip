@@ -313,5 +313,7 @@ int main() {
     run_loop<0>("consume loop as in the kernel", w, a, out, cyc, blocks);
     run_loop<1>("consume loop, no LDS reads", w, a, out, cyc, blocks);
     run_loop<4>("consume loop, LDS read inside chain", w, a, out, cyc, blocks);
+    run_loop<2>("consume loop, no max3", w, a, out, cyc, blocks);
+    run_loop<3>("consume loop, no max3, no LDS", w, a, out, cyc, blocks);
     return 0;
 }
