@@ -379,7 +379,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("PNGPD_BENCH_FORCE_GROUP") == "1":     # the second: a one-rank RCCL rehearsal
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # PNGPD_BENCH_BACKEND=gloo rehearses the multi-process flow on a box with fewer GPUs than

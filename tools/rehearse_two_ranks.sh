@@ -8,3 +8,11 @@ for wl in score train online; do
     $R/bench.py --gpus 2 --steps 20 --warmup 5 --workload $wl > $O/rehearse_$wl.log 2>&1 || { tail -30 $O/rehearse_$wl.log; exit 1; }
   grep '"metric"' $O/rehearse_$wl.log | cut -c1-260
 done
+# One rank over RCCL (a one-GPU box cannot hold two): process-group creation on the device, device-side barrier and
+# the MAX all-reduce of the timing, as in the driver's multi-GPU runs.
+export PNGPD_BENCH_BACKEND=nccl PNGPD_BENCH_FORCE_GROUP=1
+for wl in score train online; do
+  timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 \
+    $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --workload $wl > $O/rehearse_rccl_$wl.log 2>&1 || { tail -30 $O/rehearse_rccl_$wl.log; exit 1; }
+  grep '"metric"' $O/rehearse_rccl_$wl.log | cut -c1-200
+done
