@@ -502,7 +502,8 @@ def main():
             "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": f"PointNetCls {k}-class eval forward, P={P}, batch {B} per GPU, "
-                                   f"{args.precision} fused conv/max-pool kernels + fp32 FC, synthetic weights",
+                                   f"{args.precision} fused conv/max-pool kernels + "
+                                   f"{'split-bf16 (fp32-grade)' if args.precision == 'bf16' else 'fp32'} FC, synthetic weights",
                        "batch_per_gpu": B, "points": P, "classes": k, "parallelism": f"dp{n_gpus}",
                        "untimed_steps_before_timing": settle,
                        "pcie_inclusive_candidates_per_s_per_gpu": round(pcie_rate, 1), "whole_net_tflops": round(total / elapsed * flop_per_candidate(P, k) / 1e12, 2)},
