@@ -157,6 +157,196 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const float* __restrict__
     }
 }
 
+// The same Gram partials on the bf16 matrix pipe.  Every float is three bfloat16 pieces, h = hh + hm + hl to 2^-27
+// (each piece the rounded remainder of the one before), a product is the six largest of the nine piece products
+// (exact in the float32 accumulator; what is left out is below 2^-26 of the product and of either sign), and the
+// float32 accumulators, which only ever hold the sum over 64 rows, are added into double accumulators after every
+// second tile - so the sums over the rows run in double as in the kernel above, and a partial is within about 1e-7 of the
+// exact one, unbiased.  One workgroup of five waves per chunk of rows computes the ten 32x32 blocks of the 128x128
+// matrix that are not a transpose of another (wave w: row block GX_BI[w], column blocks GX_BJ[w][0..1]); waves 0-3
+// bring a tile of 32 rows in (BatchNorm + ReLU of the previous layer as above, h_out written for all columns),
+// split it and store the pieces TRANSPOSED - [piece][k-step][k half][column] x 8 consecutive rows - so that both
+// operands of v_mfma_f32_32x32x16_bf16 (each wants, per lane, 8 consecutive rows of one column) are one 16-byte LDS
+// read.  Two tile buffers, one barrier per tile.
+typedef __attribute__((ext_vector_type(8))) __bf16 gx_bf16x8;
+constexpr int GX_THREADS = 320;
+constexpr int GX_PLANE = 2 * 2 * C2 * 16;        // bytes of one piece of a 32-row tile
+
+typedef __attribute__((ext_vector_type(2))) float gx_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 gx_bf16x2;
+
+// the three pieces of two floats, each pair packed as the two halves of a word (x0 in the lower half)
+__device__ __forceinline__ void gx_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(gx_f32x2{x0, x1}, gx_bf16x2));
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(gx_f32x2{r0, r1}, gx_bf16x2));
+    const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(gx_f32x2{q0, q1}, gx_bf16x2));
+}
+
+__global__ __launch_bounds__(GX_THREADS) void gram_x6_kernel(const float* __restrict__ A, int M, int rows_per_chunk,
+                                                             double* __restrict__ part, double* __restrict__ colsum,
+                                                             const float* __restrict__ bn_mean,
+                                                             const float* __restrict__ bn_rstd,
+                                                             const float* __restrict__ bn_gamma,
+                                                             const float* __restrict__ bn_beta, float* __restrict__ h_out) {
+    __shared__ __attribute__((aligned(16))) char s_p[2][3 * GX_PLANE];
+    __shared__ double s_cs[8][C2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int row_begin = blockIdx.x * rows_per_chunk;
+    const int row_end = min(M, row_begin + rows_per_chunk);
+    // staging role (waves 0-3): rows 4rg .. 4rg+3 of the tile, columns cg + 32e
+    const bool stager = tid < 256;
+    const int cg = tid & 31, rg = (tid >> 5) & 7;
+    const int st_off = (((rg >> 2) * 2 + ((rg >> 1) & 1)) * C2) * 16 + (rg & 1) * 8;      // + column * 16
+    const bool fused = bn_mean != nullptr;
+    float mu[4], rs[4], ga[4], be[4];
+    if (fused && stager) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c0 = cg + 32 * e;
+            mu[e] = bn_mean[c0];
+            rs[e] = bn_rstd[c0];
+            ga[e] = bn_gamma[c0];
+            be[e] = bn_beta[c0];
+        }
+    }
+    // compute role: row block bi, column blocks bj0 and bj1
+    const int bi = wave == 0 || wave == 1 ? 0 : wave == 2 ? 1 : wave == 3 ? 3 : 2;
+    const int bj0 = wave == 0 ? 0 : wave == 1 ? 2 : wave == 2 ? 1 : wave == 3 ? 3 : 2;
+    const int bj1 = wave == 0 ? 1 : wave == 1 ? 3 : wave == 2 ? 2 : wave == 3 ? 1 : 3;
+    f64x4 acc[2][4];                         // [tile][register quad] as doubles: 2 x 16
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = f64x4{0.0, 0.0, 0.0, 0.0};
+    double cs[4] = {0.0, 0.0, 0.0, 0.0};
+    float v[4][4], vn[4][4];                 // [row][e]: the tile to be staged next and the one after it
+    auto load_tile = [&](int mb, float (&dst)[4][4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = mb + 4 * rg + i;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[i][e] = gm < row_end ? A[(size_t)gm * C2 + cg + 32 * e] : 0.f;
+        }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = vn[i][e];
+    };
+    auto stage = [&](int mb, char* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = mb + 4 * rg + i;
+            if (gm < row_end) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (fused) {
+                        v[i][e] = fmaxf((v[i][e] - mu[e]) * rs[e] * ga[e] + be[e], 0.f);
+                        h_out[(size_t)gm * C2 + cg + 32 * e] = v[i][e];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // rows past the end are zero; four floats are added in float before they join the double sum
+            cs[e] += (double)((v[0][e] + v[1][e]) + (v[2][e] + v[3][e]));
+            unsigned h01, m01, l01, h23, m23, l23;
+            gx_split2(v[0][e], v[1][e], h01, m01, l01);
+            gx_split2(v[2][e], v[3][e], h23, m23, l23);
+            char* dst = buf + st_off + (cg + 32 * e) * 16;
+            *(uint2*)dst = make_uint2(h01, h23);
+            *(uint2*)(dst + GX_PLANE) = make_uint2(m01, m23);
+            *(uint2*)(dst + 2 * GX_PLANE) = make_uint2(l01, l23);
+        }
+    };
+    // The pieces of tile t+1 are made and stored while the matrix pipe works on tile t (same basic block: the
+    // scheduler places the staging instructions in the shadow of the MFMAs).
+    // Rows are requested two tiles ahead: with one workgroup per CU, one tile in flight (16 KiB) keeps too little of
+    // the memory system busy.
+    if (stager && row_begin < row_end) {
+        load_tile(row_begin, v);
+        load_tile(row_begin + 32, vn);
+        stage(row_begin, s_p[0]);
+        advance();
+        load_tile(row_begin + 64, vn);
+    }
+    __syncthreads();
+    int b = 0;
+    f32x16 d0 = f32x16{0}, d1 = f32x16{0};
+    for (int mb = row_begin; mb < row_end; mb += 32, b ^= 1) {
+        const char* buf = s_p[b];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const char* base = buf + ((ks * 2 + hh) * C2 + r) * 16;
+            gx_bf16x8 a[3], b0[3], b1[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                a[pc] = *(const gx_bf16x8*)(base + pc * GX_PLANE + bi * 512);
+                b0[pc] = *(const gx_bf16x8*)(base + pc * GX_PLANE + bj0 * 512);
+                b1[pc] = *(const gx_bf16x8*)(base + pc * GX_PLANE + bj1 * 512);
+            }
+            // smallest products first
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b0[2], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b1[2], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b0[0], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b1[0], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b0[1], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b1[1], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b0[1], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b1[1], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b0[0], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b1[0], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b0[0], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b1[0], d1, 0, 0, 0);
+        }
+        if (stager && mb + 32 < row_end) {
+            stage(mb + 32, s_p[b ^ 1]);
+            advance();
+            load_tile(mb + 96, vn);
+        }
+        if (b == 1 || mb + 32 >= row_end) {       // the float accumulators hold two tiles (64 rows) at most
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[0][u][q] += (double)d0[4 * u + q];
+                    acc[1][u][q] += (double)d1[4 * u + q];
+                }
+            d0 = f32x16{0};
+            d1 = f32x16{0};
+        }
+        __syncthreads();
+    }
+    // D register t of a 32x32 block: row (t & 3) + 8 (t >> 2) + 4 hh, column r
+    double* out = part + (size_t)blockIdx.x * C2 * C2;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int bj = t == 0 ? bj0 : bj1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = bi * 32 + q + 8 * u + 4 * hh, j = bj * 32 + r;
+                out[(size_t)i * C2 + j] = acc[t][u][q];
+            }
+    }
+    if (stager) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_cs[rg][cg + 32 * e] = cs[e];
+    }
+    __syncthreads();
+    if (tid < C2) {
+        double t = 0.0;
+        for (int k = 0; k < 8; ++k) t += s_cs[k][tid];
+        colsum[(size_t)blockIdx.x * C2 + tid] = t;
+    }
+}
+
 // abar[i] = sum_chunks colsum[chunk][i] / M; block = 16 columns x 16 chunk lanes
 __global__ __launch_bounds__(256) void k_gram_mean(const double* __restrict__ colsum, int chunks, int M,
                                                    double* __restrict__ abar_d) {
@@ -177,12 +367,13 @@ __global__ __launch_bounds__(256) void k_gram_mean(const double* __restrict__ co
 // 16th chunk, the lane sums are added in a fixed order.
 __global__ __launch_bounds__(256) void k_gram_finalize(const double* __restrict__ part, int chunks,
                                                        const double* __restrict__ abar_d, int M,
-                                                       double* __restrict__ cov) {
+                                                       double* __restrict__ cov, unsigned present) {
     __shared__ double sh[16][16];
     const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int idx = blockIdx.x * 16 + el;
     const int i = idx / C2, j = idx - i * C2;
-    const int src = (i >= 64 && j < 64) ? j * C2 + i : idx;      // the block that was not computed: by symmetry
+    // `present` bit 4 (i / 32) + j / 32: that 32x32 block was computed; the others are transposes of computed ones
+    const int src = (present >> (4 * (i >> 5) + (j >> 5))) & 1u ? idx : j * C2 + i;
     double s = 0.0;
     for (int c = rl; c < chunks; c += 16) s += part[(size_t)c * C2 * C2 + src];
     sh[rl][el] = s;
@@ -815,12 +1006,20 @@ hipError_t t_conv3_fwd(float* h2, const float* W3, const float* b3, const float*
     double* colsum = gram_part + (size_t)chunks * C2 * C2;
     // y2_pre given: h2 = relu(bn2(y2_pre)) is produced by the Gram pass (and stored for the kernels after it)
     if (y2_pre != nullptr && (!bn2_mean || !bn2_rstd || !bn2_gamma || !bn2_beta)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gram_f64_kernel, dim3(3, chunks), dim3(256), 0, s, y2_pre != nullptr ? y2_pre : (const float*)h2, M,
-                       t_gram_rows_per_chunk(M), gram_part, colsum, y2_pre != nullptr ? bn2_mean : (const float*)nullptr,
-                       bn2_rstd, bn2_gamma, bn2_beta, h2);
+    // PNGPD_TRAIN_GRAM=f64 keeps the Gram product on the float64 matrix instruction (the split-bfloat16 form is the default)
+    static const bool gram_f64 = [] { const char* v = getenv("PNGPD_TRAIN_GRAM"); return v && v[0] == 'f'; }();
+    const float* gram_in = y2_pre != nullptr ? y2_pre : (const float*)h2;
+    const float* gram_mean = y2_pre != nullptr ? bn2_mean : (const float*)nullptr;
+    if (gram_f64)
+        hipLaunchKernelGGL(gram_f64_kernel, dim3(3, chunks), dim3(256), 0, s, gram_in, M, t_gram_rows_per_chunk(M), gram_part,
+                           colsum, gram_mean, bn2_rstd, bn2_gamma, bn2_beta, h2);
+    else
+        hipLaunchKernelGGL(gram_x6_kernel, dim3(chunks), dim3(GX_THREADS), 0, s, gram_in, M, t_gram_rows_per_chunk(M),
+                           gram_part, colsum, gram_mean, bn2_rstd, bn2_gamma, bn2_beta, h2);
     hipLaunchKernelGGL(k_gram_mean, dim3(C2 / 16), dim3(256), 0, s, (const double*)colsum, chunks, M, w.abar_d);
+    // 32x32 blocks of a partial that its kernel wrote (bit 4 i + j)
     hipLaunchKernelGGL(k_gram_finalize, dim3(C2 * C2 / 16), dim3(256), 0, s, (const double*)gram_part, chunks,
-                       (const double*)w.abar_d, M, w.cov);
+                       (const double*)w.abar_d, M, w.cov, gram_f64 ? 0xCCFFu : 0xAC6Fu);
     hipLaunchKernelGGL(k_conv3_stats_pack, dim3(C3), dim3(128), 0, s, W3, b3, gamma, beta, (const double*)w.cov,
                        (const double*)w.abar_d, M, momentum, mean, rstd, running_mean, running_var, w.w3p, w.w3s, w.sh);
     // enough workgroups for two per CU: split the channels of a candidate when the batch is small
