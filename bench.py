@@ -480,7 +480,7 @@ def main():
     # gfx950) that cannot run inside this process; the committed measurement is reported when it is
     # for this exact configuration, else null.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_conv_stack_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r2_conv_stack_traffic.json")
     if os.path.exists(tpath):
         t = json.load(open(tpath))
         if t["config"] == {"B": B, "P": P, "precision": args.precision}:
