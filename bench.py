@@ -223,7 +223,7 @@ def online_workload(args, dev, rank, n_gpus, dist):
 
 
 def train_workload(args, dev, rank, n_gpus, dist):
-    """Config 4: training step (fwd + bwd, NLL, Adam), P=750, batch 256 per GPU, flat-bucket all-reduce."""
+    """Config 4: training step (fwd + bwd, NLL, Adam), P=750, batch 256 per GPU, three gradient buckets all-reduced."""
     from pointnetgpd_amd.training import Trainer
 
     B, P, k = args.train_batch, args.points, args.classes
@@ -272,14 +272,14 @@ def train_workload(args, dev, rank, n_gpus, dist):
             "config": {"workload": f"PointNetCls {k}-class train step, P={P}, batch {B} per GPU, Adam lr 0.005, "
                                    "fp32 gradient all-reduced in three buckets over RCCL",
                        "loss": round(float(loss.item()), 5), "reference_equivalent_tflops": round(flop * args.steps / elapsed / 1e12, 2)},
-            "roofline": _train_roofline(conv3_tf, conv3_ms, conv3_flop),
+            "roofline": _train_roofline(conv3_tf, conv3_ms, conv3_flop, B, P),
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_train(P, k)
         print(json.dumps(line), flush=True)
 
 
-def _train_roofline(conv3_tf, conv3_ms, conv3_flop):
+def _train_roofline(conv3_tf, conv3_ms, conv3_flop, B, P):
     """Roofline entry of the training step's dominant kernel, the fused conv3 product / max / arg-max.  Its default
     form computes float32-grade products on the bfloat16 matrix pipe: every operand is split into three bfloat16
     pieces and six piece products are accumulated, so a launch executes 6 x the algorithmic flops on
@@ -292,8 +292,15 @@ def _train_roofline(conv3_tf, conv3_ms, conv3_flop):
         peak = round(PEAK_TFLOPS["bf16"] / 6.0, 1)
         kernel = ("conv3_pool_train_x6_kernel (float32-grade products as 6 bf16 piece products on "
                   "v_mfma_f32_32x32x16_bf16; peak = dense bf16 peak / 6)")
+    # HBM bytes per launch from the committed PMC passes, when they ran this kernel at this size
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r2_train_conv3_traffic.json")
+    if os.path.exists(tpath) and peak != PEAK_TFLOPS["fp32"]:
+        t = json.load(open(tpath))
+        if t["config"] == {"B": B, "P": P}:
+            traffic = t["hbm_bytes_per_launch"]
     return {"bound": "mfma", "kernel": kernel, "achieved": round(conv3_tf, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(conv3_tf / peak, 4), "traffic": None, "kernel_ms": round(conv3_ms, 4),
+            "frac": round(conv3_tf / peak, 4), "traffic": traffic, "kernel_ms": round(conv3_ms, 4),
             "flop_per_launch": conv3_flop, "executed_bf16_tflops": round(6.0 * conv3_tf, 1) if peak != PEAK_TFLOPS["fp32"] else None}
 
 
