@@ -1007,7 +1007,9 @@ hipError_t t_conv3_fwd(float* h2, const float* W3, const float* b3, const float*
     // y2_pre given: h2 = relu(bn2(y2_pre)) is produced by the Gram pass (and stored for the kernels after it)
     if (y2_pre != nullptr && (!bn2_mean || !bn2_rstd || !bn2_gamma || !bn2_beta)) return hipErrorInvalidValue;
     // PNGPD_TRAIN_GRAM=f64 keeps the Gram product on the float64 matrix instruction (the split-bfloat16 form is the default)
-    static const bool gram_f64 = [] { const char* v = getenv("PNGPD_TRAIN_GRAM"); return v && v[0] == 'f'; }();
+    // (read at every call: a test compares the two forms within one process)
+    const char* gram_env = getenv("PNGPD_TRAIN_GRAM");
+    const bool gram_f64 = gram_env && gram_env[0] == 'f';
     const float* gram_in = y2_pre != nullptr ? y2_pre : (const float*)h2;
     const float* gram_mean = y2_pre != nullptr ? bn2_mean : (const float*)nullptr;
     if (gram_f64)

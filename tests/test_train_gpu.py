@@ -494,3 +494,29 @@ def test_config4_trainer_step_at_full_size():
             assert float(d.max()) < 1e-4, (n, float(d.max()))
             compared += int(clear.sum())
     assert compared > 100_000
+
+
+def test_gram_on_bf16_pieces_agrees_with_the_float64_gram(monkeypatch):
+    """The statistics of the two conv3 BatchNorms come from a 128x128 Gram matrix.  Its default kernel multiplies
+    three-piece bfloat16 splits on the bf16 matrix pipe and adds float32 partial sums of at most 64 rows into double;
+    PNGPD_TRAIN_GRAM=f64 selects the float64 matrix instruction.  Both from the same state on the same batch: running
+    statistics equal to 1e-6 of their largest entry (float32 storage rounds at 6e-8), log-probabilities to 2e-5."""
+    B, P, k = 48, 750, 2
+    x = torch.from_numpy(synth.candidate_points(77, B, P)).cuda()
+    out = {}
+    for variant in ("f64", "x6"):
+        monkeypatch.setenv("PNGPD_TRAIN_GRAM", variant)
+        m = PointNetCls(P, 3, k)
+        m.load_state_dict(synth.torch_state_dict(21, k, 0.02), strict=True)
+        m = m.cuda().train()
+        with torch.no_grad():
+            logp, _ = m(x)
+        torch.cuda.synchronize()
+        out[variant] = (logp.double().cpu(), {n: b.detach().double().cpu() for n, b in m.named_buffers() if n.endswith(("bn3.running_mean", "bn3.running_var"))})
+    assert len(out["x6"][1]) == 4
+    for name, ref in out["f64"][1].items():
+        got = out["x6"][1][name]
+        rel = ((got - ref).abs().max() / ref.abs().max()).item()
+        print(f"{name}: max difference relative to the largest entry {rel:.2e}")
+        assert rel <= 1e-6, (name, rel)
+    assert (out["x6"][0] - out["f64"][0]).abs().max().item() <= 2e-5
