@@ -229,6 +229,7 @@ def main(argv=None):
     from .compat import load_checkpoint
     from .pointnet import PointNetCls
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL across processes needs here
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(args.gpu)))
