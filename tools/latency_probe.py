@@ -1,12 +1,15 @@
 """Per-call latency of the batch-1 scoring shim and of small eval batches (wall clock, device synchronised)."""
+import os
+import sys
 import time
 
 import numpy as np
 import torch
 
-from pointnetgpd_amd import synth
-from pointnetgpd_amd.pointnet import PointNetCls
-from pointnetgpd_amd.scoring import score_candidates, test_network
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointnetgpd_amd import synth  # noqa: E402
+from pointnetgpd_amd.pointnet import PointNetCls  # noqa: E402
+from pointnetgpd_amd.scoring import test_network  # noqa: E402
 
 P, k = 750, 2
 m = PointNetCls(P, 3, k)
