@@ -24,6 +24,7 @@ pickles of the same structure made by the tests, not on the originals.
 from __future__ import annotations
 
 import collections
+import os
 import pickle
 import struct
 import sys
@@ -187,8 +188,9 @@ class _LegacyStorage:
 class _RestrictedUnpickler(pickle.Unpickler):
     """pickle.Unpickler that resolves nothing outside a fixed table and understands the two persistent ids above."""
 
-    def __init__(self, f, legacy_classes, encoding="utf-8"):
+    def __init__(self, f, legacy_classes, encoding="utf-8", max_storage_bytes=None):
         super().__init__(f, encoding=encoding)
+        self._budget = max_storage_bytes             # storages of a file cannot be larger than the file
         table = {
             ("collections", "OrderedDict"): collections.OrderedDict,
             ("builtins", "set"): set,                    # nn.Module._non_persistent_buffers_set (torch >= 1.6)
@@ -238,6 +240,10 @@ class _RestrictedUnpickler(pickle.Unpickler):
             key = key.decode("ascii") if isinstance(key, bytes) else str(key)
             if key not in self.storages:
                 nbytes = int(numel) * torch.empty(0, dtype=storage_type.dtype).element_size()
+                if nbytes < 0 or (self._budget is not None and nbytes > self._budget):
+                    raise pickle.UnpicklingError(f"storage {key} claims {nbytes} bytes, more than the file holds")
+                if self._budget is not None:
+                    self._budget -= nbytes
                 self.storages[key] = _LegacyStorage(torch.UntypedStorage(nbytes), storage_type.dtype)
             root = self.storages[key]
             if view is not None:
@@ -259,8 +265,10 @@ def _is_legacy_container(path) -> bool:
 def _load_legacy_container(path, legacy_classes, encoding="utf-8"):
     """The object stored in a pre-1.6 torch file, read with the restricted unpickler above."""
     with open(path, "rb") as f:
+        size = os.fstat(f.fileno()).st_size
+
         def restricted():
-            return _RestrictedUnpickler(f, legacy_classes, encoding)
+            return _RestrictedUnpickler(f, legacy_classes, encoding, max_storage_bytes=size)
         if restricted().load() != _LEGACY_MAGIC:
             raise ValueError(f"{path}: not a torch checkpoint (bad magic number)")
         if restricted().load() != _LEGACY_PROTOCOL:

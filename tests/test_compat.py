@@ -163,6 +163,18 @@ def test_legacy_reader_resolves_nothing_outside_its_table(tmp_path):
     open(cut, "wb").write(blob[:len(blob) - 1000])
     with pytest.raises((ValueError, EOFError, pickle.UnpicklingError)):
         compat.load_checkpoint(cut, device="cpu")
+    # a storage record that claims more bytes than the file holds is refused before anything is allocated:
+    # the element count of the first storage (a BININT right after its location string) is raised to 2**30
+    marker = b"cpu"
+    at = blob.index(marker, blob.index(b"storage")) + len(marker)
+    while blob[at:at + 1] not in (b"K", b"M", b"J"):          # skip the memo opcode to the count's BININT1/2/4
+        at += 1
+    width = {b"K": 1, b"M": 2, b"J": 4}[blob[at:at + 1]]
+    huge = blob[:at] + b"J" + (2 ** 30).to_bytes(4, "little") + blob[at + 1 + width:]
+    big = str(tmp_path / "huge.model")
+    open(big, "wb").write(huge)
+    with pytest.raises(pickle.UnpicklingError, match="more than the file holds"):
+        compat.load_checkpoint(big, device="cpu")
 
 
 REFERENCE = "/root/reference"
