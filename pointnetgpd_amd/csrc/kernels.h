@@ -167,7 +167,8 @@ hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, co
 hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean, const float* rstd,
                     const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
                     float* dbeta, float* dbias_zero, hipStream_t s,
-                    const float* conv1_x3 = nullptr, const float* conv1_w = nullptr, const float* conv1_b = nullptr);
+                    const float* conv1_x3 = nullptr, const float* conv1_w = nullptr, const float* conv1_b = nullptr,
+                    const float* beta = nullptr);
 
 // conv3 + BatchNorm (batch statistics) + max over points without the [M,1024] activation (train_conv3.hip)
 struct Conv3Ws {

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "train_act.h"
 
 namespace pngpd {
 
@@ -124,15 +125,17 @@ __global__ __launch_bounds__(256) void k_conv1_bn_fwd(const float* __restrict__ 
     const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
     for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += gridDim.x * 4) {
         const float* xr = X3 + (size_t)m * 3;
-        const float y = w0 * xr[0] + w1 * xr[1] + w2 * xr[2] + bb;
-        h1[(size_t)m * 64 + c] = fmaxf((y - mu) * rs * ga + be, 0.f);
+        const float y = conv1_pre(w0, w1, w2, bb, xr[0], xr[1], xr[2]);
+        h1[(size_t)m * 64 + c] = fmaxf(bn_pre(y, mu, rs, ga, be), 0.f);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // column reductions over the rows of [M, C] matrices (two-stage, double accumulation of partials)
 //   mode 0 (statistics): s1 = sum(a - a0), s2 = sum((a - a0)^2), a0 = A[0][c] (shift against cancellation)
-//   mode 1 (bn backward): s1 = sum(g), s2 = sum(g*yhat); g = A*(H > 0) (H optional), yhat = (Y-mean)*rstd
+//   mode 1 (bn backward): s1 = sum(g), s2 = sum(g*yhat); yhat = (Y-mean)*rstd; g = A masked by the ReLU that
+//                         follows the BatchNorm: (H > 0) with the stored activation H, or, with gamma/beta given,
+//                         the sign of the recomputed pre-activation (H is then not read)
 // part: [nblk][2][C] doubles
 // ---------------------------------------------------------------------------------------------
 constexpr int RED_ROWS = 256;   // rows per block
@@ -143,7 +146,8 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ A, 
                                                    const float* __restrict__ rstd, int M, int C, int mode,
                                                    int rows_per_block, double* __restrict__ part,
                                                    const float* __restrict__ X3, const float* __restrict__ W1,
-                                                   const float* __restrict__ b1) {
+                                                   const float* __restrict__ b1, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta) {
     // X3 != nullptr (mode 1, C = 64): Y is conv1's output and is recomputed from the three coordinates of the row
     // (y = W1 x + b1) instead of being read: 12 bytes per row instead of 256
     __shared__ double red[2][256 * 4];       // [s1|s2][row lane][column of the block]
@@ -167,6 +171,9 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ A, 
             }
         } else {
             const float4 mu = *(const float4*)(mean + col), rs = *(const float4*)(rstd + col);
+            const bool remask = gamma != nullptr;         // gamma / beta are caller tensors: scalar loads
+            const float4 ga = remask ? make_float4(gamma[col], gamma[col + 1], gamma[col + 2], gamma[col + 3]) : mu;
+            const float4 be = remask ? make_float4(beta[col], beta[col + 1], beta[col + 2], beta[col + 3]) : mu;
             float wq[4][3] = {}, bq[4] = {};
             if (X3 != nullptr)
 #pragma unroll
@@ -182,14 +189,19 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ A, 
                 float4 y;
                 if (X3 != nullptr) {
                     const float x0 = X3[(size_t)r * 3], x1 = X3[(size_t)r * 3 + 1], x2 = X3[(size_t)r * 3 + 2];
-                    y.x = wq[0][0] * x0 + wq[0][1] * x1 + wq[0][2] * x2 + bq[0];
-                    y.y = wq[1][0] * x0 + wq[1][1] * x1 + wq[1][2] * x2 + bq[1];
-                    y.z = wq[2][0] * x0 + wq[2][1] * x1 + wq[2][2] * x2 + bq[2];
-                    y.w = wq[3][0] * x0 + wq[3][1] * x1 + wq[3][2] * x2 + bq[3];
+                    y.x = conv1_pre(wq[0][0], wq[0][1], wq[0][2], bq[0], x0, x1, x2);
+                    y.y = conv1_pre(wq[1][0], wq[1][1], wq[1][2], bq[1], x0, x1, x2);
+                    y.z = conv1_pre(wq[2][0], wq[2][1], wq[2][2], bq[2], x0, x1, x2);
+                    y.w = conv1_pre(wq[3][0], wq[3][1], wq[3][2], bq[3], x0, x1, x2);
                 } else {
                     y = *(const float4*)(Y + (size_t)r * C + col);
                 }
-                if (H != nullptr) {
+                if (remask) {
+                    if (!(bn_pre(y.x, mu.x, rs.x, ga.x, be.x) > 0.f)) g.x = 0.f;
+                    if (!(bn_pre(y.y, mu.y, rs.y, ga.y, be.y) > 0.f)) g.y = 0.f;
+                    if (!(bn_pre(y.z, mu.z, rs.z, ga.z, be.z) > 0.f)) g.z = 0.f;
+                    if (!(bn_pre(y.w, mu.w, rs.w, ga.w, be.w) > 0.f)) g.w = 0.f;
+                } else if (H != nullptr) {
                     const float4 hv = *(const float4*)(H + (size_t)r * C + col);
                     if (!(hv.x > 0.f)) g.x = 0.f;
                     if (!(hv.y > 0.f)) g.y = 0.f;
@@ -431,21 +443,27 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dense(float* __restrict__ dh, co
                                                       const float* __restrict__ y, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                       const float* __restrict__ m1, const float* __restrict__ m2,
-                                                      size_t n4, int C) {
+                                                      size_t n4, int C, const float* __restrict__ beta) {
+    // beta != nullptr: the ReLU mask is the sign of the recomputed pre-activation and h is not read
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const int c = (int)((i * 4) % (size_t)C);
     float4 gv = ((const float4*)dh)[i];
-    if (h != nullptr) {
+    const float4 yv = ((const float4*)y)[i];
+    const float4 mv = *(const float4*)(mean + c), rv = *(const float4*)(rstd + c);
+    const float4 ga = make_float4(gamma[c], gamma[c + 1], gamma[c + 2], gamma[c + 3]);     // caller tensor: scalar loads
+    if (beta != nullptr) {
+        if (!(bn_pre(yv.x, mv.x, rv.x, ga.x, beta[c]) > 0.f)) gv.x = 0.f;
+        if (!(bn_pre(yv.y, mv.y, rv.y, ga.y, beta[c + 1]) > 0.f)) gv.y = 0.f;
+        if (!(bn_pre(yv.z, mv.z, rv.z, ga.z, beta[c + 2]) > 0.f)) gv.z = 0.f;
+        if (!(bn_pre(yv.w, mv.w, rv.w, ga.w, beta[c + 3]) > 0.f)) gv.w = 0.f;
+    } else if (h != nullptr) {
         const float4 hv = ((const float4*)h)[i];
         if (!(hv.x > 0.f)) gv.x = 0.f;
         if (!(hv.y > 0.f)) gv.y = 0.f;
         if (!(hv.z > 0.f)) gv.z = 0.f;
         if (!(hv.w > 0.f)) gv.w = 0.f;
     }
-    const float4 yv = ((const float4*)y)[i];
-    const float4 mv = *(const float4*)(mean + c), rv = *(const float4*)(rstd + c);
-    const float4 ga = make_float4(gamma[c], gamma[c + 1], gamma[c + 2], gamma[c + 3]);     // caller tensor: scalar loads
     const float4 a1 = *(const float4*)(m1 + c), a2 = *(const float4*)(m2 + c);
     float4 o;
     o.x = ga.x * rv.x * (gv.x - a1.x - (yv.x - mv.x) * rv.x * a2.x);
@@ -465,9 +483,11 @@ __global__ __launch_bounds__(256) void k_conv1_bn_bwd_dense(float* __restrict__ 
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ m1,
-                                                            const float* __restrict__ m2, int M) {
+                                                            const float* __restrict__ m2, int M,
+                                                            const float* __restrict__ beta) {
+    // the ReLU mask is the sign of the recomputed pre-activation: h is not read
     const int col = (threadIdx.x & 15) * 4, rl = threadIdx.x >> 4;
-    float wq[4][3], bq[4], mu[4], rs[4], gr[4], a1[4], a2[4];
+    float wq[4][3], bq[4], mu[4], rs[4], gr[4], a1[4], a2[4], ga[4], be[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         wq[e][0] = W1[(col + e) * 3];
@@ -476,7 +496,9 @@ __global__ __launch_bounds__(256) void k_conv1_bn_bwd_dense(float* __restrict__ 
         bq[e] = b1[col + e];
         mu[e] = mean[col + e];
         rs[e] = rstd[col + e];
-        gr[e] = gamma[col + e] * rs[e];
+        ga[e] = gamma[col + e];
+        be[e] = beta[col + e];
+        gr[e] = ga[e] * rs[e];
         a1[e] = m1[col + e];
         a2[e] = m2[col + e];
     }
@@ -487,14 +509,13 @@ __global__ __launch_bounds__(256) void k_conv1_bn_bwd_dense(float* __restrict__ 
         if (r >= M) break;
         const float x0 = X3[(size_t)r * 3], x1 = X3[(size_t)r * 3 + 1], x2 = X3[(size_t)r * 3 + 2];
         const float4 gv = *(const float4*)(dh + (size_t)r * 64 + col);
-        const float4 hv = *(const float4*)(h + (size_t)r * 64 + col);
-        const float g[4] = {hv.x > 0.f ? gv.x : 0.f, hv.y > 0.f ? gv.y : 0.f, hv.z > 0.f ? gv.z : 0.f,
-                            hv.w > 0.f ? gv.w : 0.f};
+        const float gin[4] = {gv.x, gv.y, gv.z, gv.w};
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float y = wq[e][0] * x0 + wq[e][1] * x1 + wq[e][2] * x2 + bq[e];
-            o[e] = gr[e] * (g[e] - a1[e] - (y - mu[e]) * rs[e] * a2[e]);
+            const float y = conv1_pre(wq[e][0], wq[e][1], wq[e][2], bq[e], x0, x1, x2);
+            const float g = bn_pre(y, mu[e], rs[e], ga[e], be[e]) > 0.f ? gin[e] : 0.f;
+            o[e] = gr[e] * (g - a1[e] - (y - mu[e]) * rs[e] * a2[e]);
         }
         *(float4*)(dh + (size_t)r * 64 + col) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -866,7 +887,8 @@ hipError_t t_bn_stats(const float* A, int M, int C, float momentum, double* part
     const int nblk = t_colreduce_blocks(M);
     hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, A, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, 0,
-                       t_colreduce_rows(M), part, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+                       t_colreduce_rows(M), part, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr);
     hipLaunchKernelGGL(k_stats_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, A, M, C, momentum, mean, rstd,
                        running_mean, running_var);
     return hipGetLastError();
@@ -906,8 +928,9 @@ hipError_t t_bn_act_fwd(const float* y, const float* mean, const float* rstd, co
 hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean, const float* rstd,
                     const float* gamma, int M, int C, double* part, float* m1, float* m2, float* dgamma,
                     float* dbeta, float* dbias_zero, hipStream_t s, const float* conv1_x3, const float* conv1_w,
-                    const float* conv1_b) {
-    if (conv1_x3 != nullptr && (C != 64 || !conv1_w || !conv1_b || !h)) return hipErrorInvalidValue;
+                    const float* conv1_b, const float* beta) {
+    // beta given (the per-point layers): the ReLU mask comes from the recomputed pre-activation, h is not read
+    if (conv1_x3 != nullptr && (C != 64 || !conv1_w || !conv1_b || !beta)) return hipErrorInvalidValue;
     if (M <= FEW_ROWS_MAX && C % 16 == 0 && h != nullptr && conv1_x3 == nullptr) {
         if (M <= 256)
             hipLaunchKernelGGL(k_few_rows_bn_bwd<16>, dim3(C / 16), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, M, C,
@@ -919,15 +942,16 @@ hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean
     }
     const int nblk = t_colreduce_blocks(M);
     hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, (const float*)dh, h, y, mean, rstd, M,
-                       C, 1, t_colreduce_rows(M), part, conv1_x3, conv1_w, conv1_b);
+                       C, 1, t_colreduce_rows(M), part, conv1_x3, conv1_w, conv1_b, beta != nullptr ? gamma : (const float*)nullptr,
+                       beta);
     hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta,
                        dbias_zero);
     if (conv1_x3 != nullptr)
         hipLaunchKernelGGL(k_conv1_bn_bwd_dense, dim3((M + 255) / 256), dim3(256), 0, s, dh, h, conv1_x3, conv1_w, conv1_b,
-                           mean, rstd, gamma, (const float*)m1, (const float*)m2, M);
+                           mean, rstd, gamma, (const float*)m1, (const float*)m2, M, beta);
     else
         hipLaunchKernelGGL(k_bn_bwd_dense, grid1((size_t)M * C / 4), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, m1, m2,
-                           (size_t)M * C / 4, C);
+                           (size_t)M * C / 4, C, beta);
     return hipGetLastError();
 }
 hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s,

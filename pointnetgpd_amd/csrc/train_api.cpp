@@ -221,13 +221,15 @@ int bwd_stack(StackWs& S, const float* const* p, float* const* g, int u1, const 
     // conv2 / bn2
     HIP_TRY(pngpd::t_bn_bwd(S.dh2, S.h2, S.y2, S.mean[1], S.rstd[1], cslot(p, u1 + 1, PNGPD_F_BN_WEIGHT), M, C2, W.part,
                             W.m1, W.m2, slot(g, u1 + 1, PNGPD_F_BN_WEIGHT), slot(g, u1 + 1, PNGPD_F_BN_BIAS),
-                            slot(g, u1 + 1, PNGPD_F_BIAS), s));
+                            slot(g, u1 + 1, PNGPD_F_BIAS), s, nullptr, nullptr, nullptr,
+                            cslot(p, u1 + 1, PNGPD_F_BN_BIAS)));
     HIP_TRY(pngpd::t_gemm_tn(S.dh2, S.h1, W.tn_part, slot(g, u1 + 1, PNGPD_F_WEIGHT), M, C2, C1, s));
     HIP_TRY(pngpd::launch_tall_gemm(S.dh2, cslot(p, u1 + 1, PNGPD_F_WEIGHT), 1, nullptr, S.dh1, M, C1, C2, 0, nullptr, s));
     // conv1 / bn1
     HIP_TRY(pngpd::t_bn_bwd(S.dh1, S.h1, nullptr, S.mean[0], S.rstd[0], cslot(p, u1, PNGPD_F_BN_WEIGHT), M, C1, W.part,
                             W.m1, W.m2, slot(g, u1, PNGPD_F_BN_WEIGHT), slot(g, u1, PNGPD_F_BN_BIAS),
-                            slot(g, u1, PNGPD_F_BIAS), s, S.X3, cslot(p, u1, PNGPD_F_WEIGHT), cslot(p, u1, PNGPD_F_BIAS)));
+                            slot(g, u1, PNGPD_F_BIAS), s, S.X3, cslot(p, u1, PNGPD_F_WEIGHT), cslot(p, u1, PNGPD_F_BIAS),
+                            cslot(p, u1, PNGPD_F_BN_BIAS)));
     HIP_TRY(pngpd::t_conv1_bwd(S.dh1, S.X3, cslot(p, u1, PNGPD_F_WEIGHT), M, W.part, slot(g, u1, PNGPD_F_WEIGHT),
                                need_dX3 ? S.dX3 : nullptr, s));
     return PNGPD_OK;

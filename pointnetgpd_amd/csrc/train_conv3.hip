@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "kernels.h"
+#include "train_act.h"
 
 namespace pngpd {
 
@@ -46,10 +47,10 @@ constexpr int GR_LD = 80;       // LDS row stride in floats: the 4 k rows one in
 __device__ __forceinline__ float4 bn_relu4(const float4& y, const float4& mu, const float4& rs, const float4& ga,
                                            const float4& be) {
     float4 v;
-    v.x = fmaxf((y.x - mu.x) * rs.x * ga.x + be.x, 0.f);
-    v.y = fmaxf((y.y - mu.y) * rs.y * ga.y + be.y, 0.f);
-    v.z = fmaxf((y.z - mu.z) * rs.z * ga.z + be.z, 0.f);
-    v.w = fmaxf((y.w - mu.w) * rs.w * ga.w + be.w, 0.f);
+    v.x = fmaxf(bn_pre(y.x, mu.x, rs.x, ga.x, be.x), 0.f);
+    v.y = fmaxf(bn_pre(y.y, mu.y, rs.y, ga.y, be.y), 0.f);
+    v.z = fmaxf(bn_pre(y.z, mu.z, rs.z, ga.z, be.z), 0.f);
+    v.w = fmaxf(bn_pre(y.w, mu.w, rs.w, ga.w, be.w), 0.f);
     return v;
 }
 
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(GX_THREADS) void gram_x6_kernel(const float* __rest
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (fused) {
-                        v[i][e] = fmaxf((v[i][e] - mu[e]) * rs[e] * ga[e] + be[e], 0.f);
+                        v[i][e] = fmaxf(bn_pre(v[i][e], mu[e], rs[e], ga[e], be[e]), 0.f);
                         h_out[(size_t)gm * C2 + cg + 32 * e] = v[i][e];
                     }
                 }
