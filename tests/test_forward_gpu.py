@@ -260,3 +260,30 @@ def test_bf16_error_against_logit_magnitude():
         assert e16 <= 0.01 * max(spread, 2.0), (gain, spread, e16)
         assert e32 <= 1e-4 * max(1.0, spread / 5.0), (gain, spread, e32)
     assert rows[-1][1] > 5.0            # the sweep does reach scores where the absolute bar no longer applies
+
+
+def test_main_test_command_line(tmp_path, capsys):
+    """The command line of main_test.py on a checkpoint in the reference's container: ten draws of num_points points
+    from one cloud, scored in one batch, majority class printed; the classes equal per-draw calls of test_network."""
+    from pointnetgpd_amd import compat, scoring
+    P, k, seed = 500, 3, 61
+    m = PointNetCls(P, 3, k)
+    m.load_state_dict(synth.torch_state_dict(seed, k, 0.02), strict=True)
+    path = str(tmp_path / "pointgpd_3class.model")
+    compat.save_checkpoint(m, path, old_container=True)
+    cloud = synth.candidate_points(seed, 1, 900, "gripper")[0].T.copy()          # [900,3]
+    np.save(tmp_path / "cloud.npy", cloud)
+    result = scoring.main(["--load-model", path, "--points", str(tmp_path / "cloud.npy")])
+    out = capsys.readouterr().out
+    assert "Test result: %d" % result in out and "voting:" in out
+    model = compat.load_checkpoint(path)
+    winner, votes = scoring.vote_on_cloud(model, cloud, repeat=10, seed=5)
+    rng = np.random.default_rng(5)
+    c = cloud.astype(np.float32)
+    singles = []
+    for _ in range(10):
+        c = c[rng.choice(len(c), P, replace=len(c) < P)]
+        singles.append(int(scoring.test_network(model, c)[0][0]))
+    assert list(votes) == singles and votes.shape == (10,)
+    counts = np.bincount(votes, minlength=k)
+    assert counts[winner] == counts.max() and winner == int(np.argmax(counts))
