@@ -96,25 +96,11 @@ __device__ __forceinline__ int cell_coord(double v, double origin, double inv_ce
     return t < 0.0 ? 0 : (t > (double)(dim - 1) ? dim - 1 : (int)t);
 }
 
-__global__ void k_cell_count(const float* __restrict__ scene, int S, const GridParams* __restrict__ gp,
-                             int2* __restrict__ cell_rank, int* __restrict__ hist) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    const int ix = cell_coord((double)scene[(size_t)s * 3 + 0], gp->origin[0], gp->inv_cell, gp->dim[0]);
-    const int iy = cell_coord((double)scene[(size_t)s * 3 + 1], gp->origin[1], gp->inv_cell, gp->dim[1]);
-    const int iz = cell_coord((double)scene[(size_t)s * 3 + 2], gp->origin[2], gp->inv_cell, gp->dim[2]);
-    const int cell = ix + gp->dim[0] * (iy + gp->dim[1] * iz);
-    // one device-scope atomic per point is what this pass costs (~24 G/s); taking the rank from it here spares the
-    // regrouping pass a second one
-    cell_rank[s] = make_int2(cell, atomicAdd(&hist[cell], 1));
-}
-
 // Spatial order of the grasps for the one-pass kernel.  A grasp streams the ~4 k points of the cells around its
 // box out of the cell-sorted array (16 MB at a million points: more than the 4 MiB L2 of an XCD), so which grasps
 // run next to each other decides whether those lines come from the L2 or from beyond it.  perm[] lists the grasps
 // by the Morton code of the coarse cell (16 per axis) that holds their box centre - a counting sort by one
-// workgroup (the second workgroup of the k_scan_cells launch: both need only the grid's parameters, so the order
-// costs no launch and no time of its own); the order inside a cell is whatever the atomics give, which changes
+// workgroup (the first workgroup of the k_cell_count launch); the order inside a cell is whatever the atomics give, which changes
 // scheduling only, never results.
 constexpr int ORDER_BINS = 4096;
 
@@ -195,6 +181,35 @@ __device__ __forceinline__ void grasp_order(const double* __restrict__ frames, i
     }
 }
 
+// One point per thread: its cell, and its rank inside the cell from the counting atomic.  With `perm` given the
+// FIRST workgroup instead makes the spatial order of the grasps (grasp_order): it needs only the grid's parameters
+// and runs beside the counting workgroups, so the order costs no launch and no time of its own.
+__global__ __launch_bounds__(1024) void k_cell_count(const float* __restrict__ scene, int S,
+                                                     const GridParams* __restrict__ gp, int2* __restrict__ cell_rank,
+                                                     int* __restrict__ hist, const double* __restrict__ frames, int G,
+                                                     CropLimits L, int* __restrict__ perm) {
+    int block = blockIdx.x;
+    if (perm != nullptr) {
+        if (block == 0) {
+            __shared__ int s_wave[16];
+            __shared__ int s_bin[ORDER_BINS];
+            __shared__ unsigned short s_key[ORDER_CACHE];
+            grasp_order(frames, G, L, gp, perm, s_bin, s_wave, s_key);
+            return;
+        }
+        --block;
+    }
+    const int s = block * 1024 + threadIdx.x;
+    if (s >= S) return;
+    const int ix = cell_coord((double)scene[(size_t)s * 3 + 0], gp->origin[0], gp->inv_cell, gp->dim[0]);
+    const int iy = cell_coord((double)scene[(size_t)s * 3 + 1], gp->origin[1], gp->inv_cell, gp->dim[1]);
+    const int iz = cell_coord((double)scene[(size_t)s * 3 + 2], gp->origin[2], gp->inv_cell, gp->dim[2]);
+    const int cell = ix + gp->dim[0] * (iy + gp->dim[1] * iz);
+    // one device-scope atomic per point is what this pass costs (~24 G/s); taking the rank from it here spares the
+    // regrouping pass a second one
+    cell_rank[s] = make_int2(cell, atomicAdd(&hist[cell], 1));
+}
+
 // Position in perm[] that workgroup `b` of `n` takes: workgroups are handed to the 8 XCDs in turn, so the
 // workgroups b, b + 8, b + 16, ... share an L2; they get one contiguous eighth of the spatial order.
 __device__ __forceinline__ int xcd_contiguous(int b, int n) {
@@ -205,16 +220,8 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
 // exclusive scan of hist over the cells in use into start[0..ncells]; cursor = copy.  One block of 1024 threads
 // walks the cells in chunks of 4096 (one int4 per thread: coalesced) and carries the running total.
 __global__ __launch_bounds__(1024) void k_scan_cells(const GridParams* __restrict__ gp, const int* __restrict__ hist,
-                                                     int* __restrict__ start, int* __restrict__ cursor,
-                                                     const double* __restrict__ frames, int G, CropLimits L,
-                                                     int* __restrict__ perm) {
+                                                     int* __restrict__ start, int* __restrict__ cursor) {
     __shared__ int s_wave[16];
-    if (blockIdx.x == 1) {                              // launched only when an order is wanted
-        __shared__ int s_bin[ORDER_BINS];
-        __shared__ unsigned short s_key[ORDER_CACHE];
-        grasp_order(frames, G, L, gp, perm, s_bin, s_wave, s_key);
-        return;
-    }
     const int ncells = gp->dim[0] * gp->dim[1] * gp->dim[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int carry = 0;
@@ -797,10 +804,10 @@ static hipError_t build_grid(const float* scene, int S, const CropLimits& L, con
     if (!(cell_req > 0.0)) cell_req = 1e-3;
     hipLaunchKernelGGL(k_bounds_partial, dim3(nblk), dim3(256), 0, s, scene, S, w.part, w.hist);
     hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(256), 0, s, (const float*)w.part, nblk, cell_req, w.gp, clear_flag);
-    hipLaunchKernelGGL(k_cell_count, dim3((S + 255) / 256), dim3(256), 0, s, scene, S, (const GridParams*)w.gp,
-                       w.cell_rank, w.hist);
-    hipLaunchKernelGGL(k_scan_cells, dim3(perm != nullptr ? 2 : 1), dim3(1024), 0, s, (const GridParams*)w.gp,
-                       (const int*)w.hist, w.start, w.cursor, frames, G, L, perm);
+    hipLaunchKernelGGL(k_cell_count, dim3((S + 1023) / 1024 + (perm != nullptr ? 1 : 0)), dim3(1024), 0, s, scene, S,
+                       (const GridParams*)w.gp, w.cell_rank, w.hist, frames, G, L, perm);
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, s, (const GridParams*)w.gp, (const int*)w.hist, w.start,
+                       w.cursor);
     hipLaunchKernelGGL(k_scatter, dim3((S + 255) / 256), dim3(256), 0, s, scene, S, (const int2*)w.cell_rank,
                        (const int*)w.start, w.sorted);
     return hipGetLastError();
