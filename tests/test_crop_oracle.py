@@ -100,3 +100,44 @@ def test_vote_semantics():
     assert label == 1 and score == np.mean(np.array([0.7, 0.8], dtype=np.float32))
     label, score = co.vote([0, 1, 2], np.ones((3, 1, 3), np.float32) / 3, 3)   # three-way tie -> smallest
     assert label == 0
+
+
+REFERENCE_FILE = "/root/reference/apps/kinect2grasp.py"
+
+
+def _reference_check_collision_square():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_crop_golden", os.path.join(GOLDEN, "make_crop_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.reference_function("check_collision_square"), mod
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_FILE), reason="needs the reference checkout (build container only)")
+@pytest.mark.parametrize("seed", [3, 14, 159, 2653])
+def test_live_against_the_reference_function_on_fresh_random_cases(seed):
+    """Beyond the committed vectors: in the build container the reference's own check_collision_square (taken out of
+    its file's syntax tree, numpy its only global) runs next to the restatement on cases drawn here - oblique grasps
+    with axes of random length, scenes of mixed density, a few points pushed to within ulps of a plane - and both
+    forms of the restatement return the same index lists and the same float64 coordinates, bit for bit."""
+    fn, mod = _reference_check_collision_square()
+    rng = np.random.default_rng(seed)
+    S, G, cube = int(rng.integers(500, 4000)), 12, 0.2
+    p = co.hand_points(hand_depth=0.06, hand_outer_diameter=0.12, finger_width=0.02, hand_height=0.02)   # near_plane_case's
+    limits = co.box_limits(p)
+    scene = synth.scene_points(seed, S, cube)
+    grasps = synth.random_grasps(seed, G, cube, 0.03).reshape(G, 5, 3).copy()
+    grasps[:, 1:4, :] *= rng.uniform(0.3, 3.0, size=(G, 3, 1))
+    ng, nscene, _ = mod.near_plane_case(seed=seed, G=2, per_plane=6)
+    grasps = np.concatenate([grasps, ng.reshape(-1, 5, 3)])
+    scene = np.vstack([scene, nscene]).astype(np.float32)
+    ref_idx, ref_pts = mod.reference_collect_pc(grasps, scene, p)
+    for form in (co.crop_numpy, co.crop_c):
+        idx, pts = form(grasps, scene, limits)
+        assert sum(len(i) for i in idx) > 0
+        for g in range(len(grasps)):
+            np.testing.assert_array_equal(idx[g], ref_idx[g])
+            np.testing.assert_array_equal(pts[g], ref_pts[g])

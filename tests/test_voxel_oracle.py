@@ -89,3 +89,40 @@ def test_float64_edge_form_differs_from_it_only_in_the_last_bit():
         if got.shape == want.shape:
             scale = np.abs(want).max()
             assert np.abs(got - want).max() <= 2 * np.spacing(np.float32(scale))
+
+
+import os  # noqa: E402
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/apps/voxelgrid.py"),
+                    reason="needs the reference checkout (build container only)")
+@pytest.mark.parametrize("seed", [4, 25, 611])
+def test_live_against_the_reference_definitions_on_fresh_clouds(seed):
+    """Beyond the committed vectors: in the build container the reference's own cartesian / VoxelGrid /
+    get_voxel_fun (taken out of the syntax trees of its files, numpy their only global) run next to the restatement on
+    clouds drawn here, including points placed exactly on bin edges; same unique centres, bit for bit (float32-edge
+    form: this image has numpy 2)."""
+    import importlib.util
+    import sys
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, golden)
+    try:
+        spec = importlib.util.spec_from_file_location("make_voxel_golden", os.path.join(golden, "make_voxel_golden.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path.remove(golden)
+    ref = mod.reference_get_voxel_fun()
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(3, 60))
+    S = int(rng.integers(200, 5000))
+    pts = (rng.normal(size=(S, 3)) * rng.uniform(0.02, 0.5, size=3) + rng.uniform(-1, 1, size=3)).astype(np.float32)
+    lo, hi = pts.min(0), pts.max(0)
+    on_edges = lo + (hi - lo).max() * (rng.integers(0, n + 1, size=(40, 3)) / n)     # about on the edges of the cubic box
+    pts = np.vstack([pts, on_edges.astype(np.float32)])
+    want = np.asarray(ref(pts, n))
+    got = vo.get_voxel_fun(pts, n, edges="float32" if int(np.__version__.split(".")[0]) >= 2 else "float64")
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
