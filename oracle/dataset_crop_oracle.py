@@ -3,9 +3,13 @@ by the product path.
 
 collect_pc_ (model/dataset.py:767-924, the `their_way = False` branch, projection off) and the
 resampling / labelling of PointGraspOneViewDataset.__getitem__ (:1098-1131), per grasp record, with
-the reference's numpy calls.  PARITY UNPINNED: model/dataset.py imports pcl, dexnet and autolab_core
-at module level (none present in this image) and reads YCB data from disk; the reference holds no
-fixture for it.  ags.gripper.hand_depth and the corner table of ags.get_hand_points are arguments.
+the reference's numpy calls.  model/dataset.py imports pcl, dexnet and autolab_core at module level (none
+present in this image) and reads YCB data from disk, and the reference holds no fixture for it.
+PINNED as far as the reference can run here: frame_of_record and the gripper-frame coordinates equal, bit
+for bit, what the reference's own statements :776-843 return (tests/golden/make_dataset_golden.py takes them out
+of the method's syntax tree; tests/golden/dataset_frames_reference.npz).  The six comparisons are those of the
+online crop, pinned by its own reference run.  PARITY UNPINNED for the rest: the corner table of dex-net's
+get_hand_points (an argument here) and the resampling / labelling tail.  ags.gripper.hand_depth is an argument.
 """
 import numpy as np
 

@@ -2,7 +2,7 @@
 C ABI) against the restatement of collect_pc_ + __getitem__ (model/dataset.py:767-924, 1098-1131):
 index sets and gripper-frame float64 coordinates bit-exact for given frames, resampled float32 input bit-exact
 for given draws; the frames the device builds from grasp records (pngpd_dataset_frames) within a stated bound of
-the restatement's.  The restatement is unpinned (the reference module needs pcl/dexnet and YCB data)."""
+the restatement's and of a run of the reference's own statements (tests/golden/dataset_frames_reference.npz)."""
 import numpy as np
 import pytest
 import torch
@@ -172,3 +172,18 @@ def test_make_training_batch_feeds_the_network_layout():
     d = batch.data.double().cpu().numpy()
     assert (d[:, 1] > limits[0] - 1e-6).all() and (d[:, 1] < limits[1] + 1e-6).all()
     assert (d[:, 0] > limits[4] - 1e-6).all() and (d[:, 0] < limits[5] + 1e-6).all()
+
+
+def test_device_frames_match_the_reference_run():
+    """The same records and transforms as tests/golden/dataset_frames_reference.npz (outputs of the reference's own
+    statements, model/dataset.py:776-843): the frames the device builds lie within the stated bound of them."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_frames_reference.npz"))
+    rec, hd = d["records"], float(d["hand_depth"])
+    for name in ("rigid", "sheared"):
+        T = d[f"transform_{name}"]
+        got = dc.frames_from_configs(rec, T, hd).cpu().numpy()
+        want = np.concatenate([d[f"bottom_{name}"], d[f"matrix_{name}"].reshape(len(rec), 9)], axis=1)
+        err = np.abs(got - want).max()
+        print(f"{name}: max |device - reference| = {err:.2e}")
+        assert err <= FRAME_TOL * max(1.0, np.abs(want).max()), err

@@ -92,3 +92,22 @@ def test_restatement_regression_vectors():
         assert len(ind) == int(d["counts"][g])
         if len(ind) >= 4:
             np.testing.assert_array_equal(gpc[:4], d["first_points"][g])
+
+
+def test_frames_and_local_coordinates_equal_the_reference_run():
+    """tests/golden/dataset_frames_reference.npz holds what the reference's own statements of collect_pc_
+    (model/dataset.py:776-843, taken out of the method's syntax tree and run by tests/golden/make_dataset_golden.py)
+    return for 40 grasp records - axes along z, along x and y, of arbitrary length, angles 0 and pi/2 among them -
+    under a rigid and a sheared 4x4 transform: `matrix`, `bottom_` and the gripper-frame coordinates of 96 points.
+    The restatement returns the same doubles, bit for bit."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_frames_reference.npz"))
+    rec, pc, hd = d["records"], d["pc"], float(d["hand_depth"])
+    for name in ("rigid", "sheared"):
+        T = d[f"transform_{name}"]
+        frames = do.frames_of_records(rec, T, hd)
+        np.testing.assert_array_equal(frames[:, :3], d[f"bottom_{name}"])
+        np.testing.assert_array_equal(frames[:, 3:].reshape(-1, 3, 3), d[f"matrix_{name}"])
+        for g, r in enumerate(rec):
+            bottom_, matrix = do.frame_of_record(r, T, hd)
+            np.testing.assert_array_equal((np.dot(matrix, (pc - bottom_).T)).T, d[f"pc_c2g_{name}"][g])
