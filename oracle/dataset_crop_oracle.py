@@ -8,8 +8,9 @@ present in this image) and reads YCB data from disk, and the reference holds no 
 PINNED as far as the reference can run here: frame_of_record and the gripper-frame coordinates equal, bit
 for bit, what the reference's own statements :776-843 return (tests/golden/make_dataset_golden.py takes them out
 of the method's syntax tree; tests/golden/dataset_frames_reference.npz).  The six comparisons are those of the
-online crop, pinned by its own reference run.  PARITY UNPINNED for the rest: the corner table of dex-net's
-get_hand_points (an argument here) and the resampling / labelling tail.  ags.gripper.hand_depth is an argument.
+online crop, pinned by its own reference run; getitem_tail equals a run of the statements :1098-1131 with
+numpy's generator seeded alike (tests/golden/dataset_tail_reference.npz).  PARITY UNPINNED: the corner table of
+dex-net's get_hand_points (an argument here).  ags.gripper.hand_depth is an argument.
 """
 import numpy as np
 

@@ -58,6 +58,42 @@ def reference_frame_part(path=REFERENCE_FILE):
     return ns["frame_part"]
 
 
+def reference_getitem_tail(path=REFERENCE_FILE):
+    """The statements of PointGraspOneViewDataset.__getitem__ after collect_pc_ (model/dataset.py:1098-1131: the
+    None check, resampling to grasp_points_num points, the score and the label) as a function of
+    (self, grasp, grasp_pc, obj_grasp); `self` only carries the dataset's own numbers (projection, grasp_points_num,
+    thresh_good, thresh_bad, with_obj)."""
+    with open(path, encoding="utf-8") as f:
+        tree = ast.parse(f.read(), filename=path)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "PointGraspOneViewDataset"][0]
+    fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__getitem__"][0]
+    start = None
+    for i, stmt in enumerate(fn.body):
+        if isinstance(stmt, ast.Assign) and any(isinstance(t, ast.Name) and t.id == "grasp_pc" for t in stmt.targets):
+            start = i + 1                                  # the statement after `grasp_pc = self.collect_pc_(...)`
+    assert start is not None
+    body = [st for st in fn.body[start:]
+            if not (isinstance(st, ast.Expr) and isinstance(st.value, ast.Constant) and isinstance(st.value.value, str))]
+    args = ast.arguments(posonlyargs=[], args=[ast.arg(arg=a) for a in ("self", "grasp", "grasp_pc", "obj_grasp")],
+                         kwonlyargs=[], kw_defaults=[], defaults=[])
+    func = ast.FunctionDef(name="getitem_tail", args=args, body=body, decorator_list=[], lineno=fn.lineno, col_offset=0)
+    module = ast.fix_missing_locations(ast.Module(body=[func], type_ignores=[]))
+    ns = {"np": np, "__name__": "reference_extract"}
+    exec(compile(module, path, "exec"), ns)
+    return ns["getitem_tail"]
+
+
+def tail_cases(seed=17, N=64):
+    rng = np.random.default_rng(seed)
+    out = []
+    for n, level, refine in ((200, 0.1, 0.2), (N + 1, 0.9, 0.5), (N, 0.3, 1.0), (N - 1, 0.55, 0.0), (50, 0.6, 0.0),
+                             (57, 0.4, 20.0), (300, 0.5, 0.0)):
+        pc = rng.normal(size=(n, 3))
+        grasp = np.concatenate([rng.normal(size=8), [level, refine]])
+        out.append((grasp, pc))
+    return out, N, 0.5, 0.6                                 # thresh_good, thresh_bad (main_1v.py:34-35 style values)
+
+
 def cases(seed=91, G=40, S=96):
     rng = np.random.default_rng(seed)
     rec = np.zeros((G, 10))
@@ -102,6 +138,22 @@ def main():
         out[f"pc_c2g_{name}"] = np.stack(local)
         print(name, "matrix", out[f"matrix_{name}"].shape, "pc_c2g", out[f"pc_c2g_{name}"].shape)
     np.savez_compressed(os.path.join(HERE, "dataset_frames_reference.npz"), **out)
+
+    tail = reference_getitem_tail()
+    tcases, N, good, bad = tail_cases()
+    self_ = types.SimpleNamespace(projection=False, grasp_points_num=N, thresh_good=good, thresh_bad=bad, with_obj=False)
+    t = {"N": N, "thresh_good": good, "thresh_bad": bad, "count": len(tcases)}
+    for i, (grasp, pc) in enumerate(tcases):
+        np.random.seed(1000 + i)
+        res = tail(self_, grasp, pc, "obj")
+        t[f"grasp_{i}"] = grasp
+        t[f"pc_{i}"] = pc
+        t[f"kept_{i}"] = res is not None
+        if res is not None:
+            t[f"out_{i}"] = np.asarray(res[0])
+            t[f"label_{i}"] = res[1]
+        print("tail case", i, "n =", len(pc), "->", None if res is None else (np.asarray(res[0]).shape, res[1]))
+    np.savez_compressed(os.path.join(HERE, "dataset_tail_reference.npz"), **t)
 
 
 if __name__ == "__main__":

@@ -111,3 +111,24 @@ def test_frames_and_local_coordinates_equal_the_reference_run():
         for g, r in enumerate(rec):
             bottom_, matrix = do.frame_of_record(r, T, hd)
             np.testing.assert_array_equal((np.dot(matrix, (pc - bottom_).T)).T, d[f"pc_c2g_{name}"][g])
+
+
+def test_getitem_tail_equals_the_reference_run():
+    """tests/golden/dataset_tail_reference.npz: the statements of PointGraspOneViewDataset.__getitem__ after
+    collect_pc_ (model/dataset.py:1098-1131), taken out of the method and run with numpy's global generator seeded per
+    case - clouds of more than, exactly, and fewer than grasp_points_num points; scores on both sides of and between
+    the two thresholds.  The restatement, drawing from the same seeded generator, returns the same arrays and labels."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_tail_reference.npz"))
+    N, good, bad = int(d["N"]), float(d["thresh_good"]), float(d["thresh_bad"])
+    kept = 0
+    for i in range(int(d["count"])):
+        np.random.seed(1000 + i)
+        res = do.getitem_tail(d[f"grasp_{i}"], d[f"pc_{i}"], N, good, bad,
+                              lambda n, size, replace: np.random.choice(n, size=size, replace=replace))
+        assert (res is not None) == bool(d[f"kept_{i}"])
+        if res is not None:
+            kept += 1
+            np.testing.assert_array_equal(res[0], d[f"out_{i}"])
+            assert res[1] == int(d[f"label_{i}"])
+    assert 0 < kept < int(d["count"])
