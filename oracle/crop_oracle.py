@@ -15,7 +15,9 @@ its outputs as tests/golden/crop_*.npz.  tests/test_crop_oracle.py checks every 
 bit for bit: `crop_numpy` keeps the reference's numpy calls (np.linalg.norm, np.dot of a 3x3 by 3xS matrix);
 `crop_pinned` spells out the operation order that those calls execute on the build container's numpy/OpenBLAS
 (a k-ordered fused-multiply-add chain) with no library call left; oracle/crop_oracle.c is the same pinned
-order in C (used for large inputs).  Subsample and vote restate scalar logic and have no reference-run fixture.
+order in C (used for large inputs).  `subsample` and the score half of `vote` equal a run of the reference's own
+statements (:766-774, :803-817; tests/golden/crop_loop_reference.npz); the vote's `mode(predict)[0][0]` is not
+evaluable under this image's scipy, its rule (smallest of the most frequent classes) is restated, unpinned.
 
 The gripper corner table comes from dex-net's get_hand_points (an un-vendored dependency,
 github.com/Hymwgk/dex-net, no pinned revision); `hand_points` restates its published construction

@@ -61,6 +61,49 @@ def reference_collect_pc(grasps, scene, p):
     return in_ind, in_ind_points
 
 
+def reference_loop_statements(path=REFERENCE_FILE):
+    """Three statements of the scoring loop in the reference's `__main__` block (apps/kinect2grasp.py:766-774,
+    803-817), taken out of the syntax tree and wrapped in two functions with numpy as their only global:
+    draw(in_ind_points, ii, input_points_num) -> points_modify   (the with / without replacement rule), and
+    mean_score(predict, predict_vote, grasp_score, args) -> (which_one_is_best, score_vote).
+    The vote itself, `mode(predict)[0][0]`, is not among them: scipy >= 1.11 returns a scalar there."""
+    with open(path, encoding="utf-8") as f:
+        tree = ast.parse(f.read(), filename=path)
+    draw_if = [n for n in ast.walk(tree) if isinstance(n, ast.If)
+               and ast.unparse(n.test) == "len(in_ind_points[ii]) >= input_points_num"]
+    best_if = [n for n in ast.walk(tree) if isinstance(n, ast.If) and ast.unparse(n.test) == "args.model_type == '3class'"
+               and any(isinstance(t, ast.Name) and t.id == "which_one_is_best"
+                       for st in n.body if isinstance(st, ast.Assign) for t in st.targets)]
+    score = [n for n in ast.walk(tree) if isinstance(n, ast.Assign)
+             and any(isinstance(t, ast.Name) and t.id == "score_vote" for t in n.targets)]
+    assert len(draw_if) == 1 and len(best_if) == 1 and len(score) == 1, (len(draw_if), len(best_if), len(score))
+
+    def wrap(name, params, body, returns):
+        ret = ast.Return(value=ast.Tuple(elts=[ast.Name(id=r, ctx=ast.Load()) for r in returns], ctx=ast.Load())
+                         if len(returns) > 1 else ast.Name(id=returns[0], ctx=ast.Load()))
+        args = ast.arguments(posonlyargs=[], args=[ast.arg(arg=a) for a in params], kwonlyargs=[], kw_defaults=[],
+                             defaults=[])
+        return ast.FunctionDef(name=name, args=args, body=list(body) + [ret], decorator_list=[], lineno=1, col_offset=0)
+
+    funcs = [wrap("draw", ("in_ind_points", "ii", "input_points_num"), draw_if, ("points_modify",)),
+             wrap("mean_score", ("predict", "predict_vote", "grasp_score", "args"), best_if + score,
+                  ("which_one_is_best", "score_vote"))]
+    module = ast.fix_missing_locations(ast.Module(body=funcs, type_ignores=[]))
+    ns = {"np": np, "__name__": "reference_extract"}
+    exec(compile(module, path, "exec"), ns)
+    return ns["draw"], ns["mean_score"]
+
+
+def loop_cases(seed=33, P=40):
+    rng = np.random.default_rng(seed)
+    clouds = [rng.normal(size=(n, 3)) for n in (P + 25, P + 1, P, P - 1, 20, 21)]
+    votes = []
+    for k, preds in ((2, [1, 1, 0]), (2, [0, 1, 0]), (2, [1, 1, 1]), (3, [2, 0, 2]), (3, [0, 1, 2]), (3, [2, 2, 1, 1, 0]),
+                     (2, [0, 0, 1, 1])):
+        votes.append((k, preds, rng.random((len(preds), 1, k)).astype(np.float32)))
+    return clouds, P, votes
+
+
 def adversarial_case():
     """Axis-aligned grasps with float32-exact centres plus points exactly on / one ulp either side of each plane."""
     p = co.hand_points(**HAND)
@@ -148,5 +191,26 @@ def main():
                         pts_sha256=np.array([hashlib.sha256(np.ascontiguousarray(q).tobytes()).hexdigest() for q in pts]))
 
 
+def loop_main():
+    import types
+    draw, mean_score = reference_loop_statements()
+    clouds, P, votes = loop_cases()
+    out = {"P": P, "n_clouds": len(clouds), "n_votes": len(votes)}
+    for i, c in enumerate(clouds):
+        np.random.seed(500 + i)
+        out[f"cloud_{i}"] = c
+        out[f"drawn_{i}"] = draw([c], 0, P)
+    for i, (k, preds, probs) in enumerate(votes):
+        values, counts = np.unique(preds, return_counts=True)
+        label = values[np.argmax(counts)]                       # what scipy.stats.mode returns: smallest of the most common
+        args = types.SimpleNamespace(model_type="3class" if k == 3 else "750")
+        best, score_vote = mean_score(list(preds), label, np.array(list(probs)), args)
+        out[f"k_{i}"], out[f"preds_{i}"], out[f"probs_{i}"] = k, np.array(preds), probs
+        out[f"label_{i}"], out[f"best_{i}"], out[f"score_{i}"] = label, best, score_vote
+        print("vote case", i, preds, "->", label, best, score_vote)
+    np.savez_compressed(os.path.join(HERE, "crop_loop_reference.npz"), **out)
+
+
 if __name__ == "__main__":
     main()
+    loop_main()

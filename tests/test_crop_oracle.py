@@ -141,3 +141,27 @@ def test_live_against_the_reference_function_on_fresh_random_cases(seed):
         for g in range(len(grasps)):
             np.testing.assert_array_equal(idx[g], ref_idx[g])
             np.testing.assert_array_equal(pts[g], ref_pts[g])
+
+
+def test_draw_rule_and_vote_score_equal_the_reference_statements():
+    """tests/golden/crop_loop_reference.npz: three statements of the reference's scoring loop (apps/kinect2grasp.py:
+    766-774 and 803-817), taken out of its `__main__` block and run: the draw of input_points_num points (without
+    replacement when the grasp holds at least that many, with replacement below) under numpy's seeded generator, and
+    the best-class rule with the mean score over the repeats that agree with the vote.  The vote itself is
+    `mode(predict)[0][0]`, which scipy >= 1.11 no longer evaluates; its rule (smallest of the most frequent) is
+    supplied to both sides."""
+    d = np.load(os.path.join(GOLDEN, "crop_loop_reference.npz"))
+    P = int(d["P"])
+    below = 0
+    for i in range(int(d["n_clouds"])):
+        cloud = d[f"cloud_{i}"]
+        np.random.seed(500 + i)
+        sel = np.random.choice(len(cloud), P, replace=len(cloud) < P)
+        np.testing.assert_array_equal(co.subsample(cloud, sel), d[f"drawn_{i}"])
+        below += len(cloud) < P
+    assert 0 < below < int(d["n_clouds"])
+    for i in range(int(d["n_votes"])):
+        label, score = co.vote(d[f"preds_{i}"], d[f"probs_{i}"], int(d[f"k_{i}"]))
+        assert label == int(d[f"label_{i}"])
+        assert (2 if int(d[f"k_{i}"]) == 3 else 1) == int(d[f"best_{i}"])
+        assert score == d[f"score_{i}"] and np.asarray(score).dtype == d[f"score_{i}"].dtype
