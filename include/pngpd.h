@@ -36,9 +36,14 @@ enum {
     PNGPD_ERR_WORKSPACE = 5  /* workspace smaller than pngpd_*_workspace_bytes()     */
 };
 
-/* arithmetic of the two fused conv stacks: exact-f32 MFMA, or bf16 operands with f32 accumulation.  The FC layers
- * give f32-grade results in both modes (f32 MFMA; split-bf16 products, hi + lo operands, in BF16 mode). */
-enum { PNGPD_FP32 = 0, PNGPD_BF16 = 1 };
+/* arithmetic of the two fused conv stacks:
+ *   PNGPD_FP32    exact-f32 MFMA (every product an f32 fma chain);
+ *   PNGPD_BF16    bf16 operands, f32 accumulation: the error of a log-probability is about 0.4 % of the class
+ *                 scores' magnitude;
+ *   PNGPD_BF16X3  split-bf16 operands (hi + lo pieces, three bf16 MFMAs per product, f32 accumulation): f32-grade
+ *                 results (operands exact to 2^-18) at a third of the bf16 rate.
+ * The FC layers give f32-grade results in every mode (f32 MFMA in FP32, split-bf16 products otherwise). */
+enum { PNGPD_FP32 = 0, PNGPD_BF16 = 1, PNGPD_BF16X3 = 2 };
 
 /* memory layout of the candidate points */
 enum {
@@ -107,7 +112,7 @@ size_t pngpd_forward_workspace_bytes(const pngpd_model* m, int B);
  *   all three     : logp_dev, trans_dev (, feat_dev)= PointNetCls.forward  (model/pointnet.py:185-190)
  * x_dev: float32, layout PNGPD_LAYOUT_*; P must equal num_points.
  * logp_dev [B,k] log-probabilities, trans_dev [B,3,3], feat_dev [B,1024]; any of them may be NULL
- * when the caller does not want it.  `precision` selects PNGPD_FP32 (exact-f32 MFMA) or PNGPD_BF16.
+ * when the caller does not want it.  `precision` is one of PNGPD_FP32, PNGPD_BF16, PNGPD_BF16X3.
  */
 int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, int B, int P,
                         int precision, float* logp_dev, float* trans_dev, float* feat_dev,

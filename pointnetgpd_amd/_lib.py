@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpngpd.so")
 
 OK = 0
-FP32, BF16 = 0, 1
+FP32, BF16, BF16X3 = 0, 1, 2
 LAYOUT_C3P, LAYOUT_P3 = 0, 1
 PART_STN, PART_TRUNK, PART_HEAD = 1, 2, 4
 NOALLOC_MAX_B = 256
@@ -19,7 +19,7 @@ UNITS = ("stn_conv1", "stn_conv2", "stn_conv3", "stn_fc1", "stn_fc2", "stn_fc3",
 FIELDS = ("weight", "bias", "bn_weight", "bn_bias", "bn_mean", "bn_var")
 SLOTS = len(UNITS) * len(FIELDS)
 
-PRECISIONS = {"fp32": FP32, "float32": FP32, "bf16": BF16, "bfloat16": BF16}
+PRECISIONS = {"fp32": FP32, "float32": FP32, "bf16": BF16, "bfloat16": BF16, "bf16x3": BF16X3}
 
 
 class PngpdError(RuntimeError):

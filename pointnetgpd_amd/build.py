@@ -22,7 +22,9 @@ ARCH = "gfx950"
 LIB_SOURCES = [
     "api.cpp",
     "pack.cpp",
+    "launch_util.cpp",
     "conv_stack.hip",
+    "conv_stack_x3.hip",
     "fc.hip",
     "crop.hip",
     "crop_grid.hip",

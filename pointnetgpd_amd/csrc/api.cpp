@@ -55,7 +55,7 @@ struct DevBuf {
 };
 
 struct StackDev {
-    DevBuf w1tab, b2p, b2, b3, w2_bf16, w3_bf16, w2_f32, w3_f32;
+    DevBuf w1tab, b2p, b2, b3, w2_bf16, w3_bf16, w2_lo, w3_lo, w2_f32, w3_f32;
 };
 
 struct FcDev {
@@ -107,6 +107,8 @@ int load_stack(const float* const* t, int u_conv1, StackDev& d, std::vector<Pack
     HIP_TRY(d.b3.upload(p.b3.data(), p.b3.size() * 4, s));
     HIP_TRY(d.w2_bf16.upload(p.w2_bf16.data(), p.w2_bf16.size() * 2, s));
     HIP_TRY(d.w3_bf16.upload(p.w3_bf16.data(), p.w3_bf16.size() * 2, s));
+    HIP_TRY(d.w2_lo.upload(p.w2_lo.data(), p.w2_lo.size() * 2, s));
+    HIP_TRY(d.w3_lo.upload(p.w3_lo.data(), p.w3_lo.size() * 2, s));
     HIP_TRY(d.b2.upload(p.b2.data(), p.b2.size() * 4, s));
     HIP_TRY(d.w2_f32.upload(p.w2_f32.data(), p.w2_f32.size() * 4, s));
     HIP_TRY(d.w3_f32.upload(p.w3_f32.data(), p.w3_f32.size() * 4, s));
@@ -155,7 +157,7 @@ struct Workspace {
 
 int run_fc_chain(const FcDev& fc, const float* in, Workspace& ws, float* out, int B, int tail, int precision,
                  hipStream_t s) {
-    if (precision == PNGPD_BF16) {
+    if (precision != PNGPD_FP32) {
         // split-bf16 products: f32-grade results on the bf16 matrix pipe
         HIP_TRY(pngpd::launch_fc_bf16x3(in, fc.wsplit[0].p, (const float*)fc.b[0].p, ws.h512, B, fc.n[0], fc.k[0], 1, s));
         HIP_TRY(pngpd::launch_fc_bf16x3(ws.h512, fc.wsplit[1].p, (const float*)fc.b[1].p, ws.h256, B, fc.n[1], fc.k[1],
@@ -180,9 +182,14 @@ pngpd::ConvStackArgs stack_args(const StackDev& d, int precision, const float* x
     a.P = P;
     a.w1tab = (const float4*)d.w1tab.p;
     a.trans = trans;
-    a.w2p = precision == PNGPD_BF16 ? d.w2_bf16.p : d.w2_f32.p;
-    a.b2p = (const float*)(precision == PNGPD_BF16 ? d.b2.p : d.b2p.p);
-    a.w3p = precision == PNGPD_BF16 ? d.w3_bf16.p : d.w3_f32.p;
+    const bool f32 = precision == PNGPD_FP32;
+    a.w2p = f32 ? d.w2_f32.p : d.w2_bf16.p;
+    a.b2p = (const float*)(f32 ? d.b2p.p : d.b2.p);
+    a.w3p = f32 ? d.w3_f32.p : d.w3_bf16.p;
+    if (precision == PNGPD_BF16X3) {
+        a.w2lo = d.w2_lo.p;
+        a.w3lo = d.w3_lo.p;
+    }
     a.b3 = (const float*)d.b3.p;
     a.pooled = pooled;
     a.relu_out = relu_out;
@@ -322,7 +329,7 @@ static int forward_impl(const pngpd_model* m, const float* x_dev, int layout, in
                     P, m->num_points);
     if (layout != PNGPD_LAYOUT_C3P && layout != PNGPD_LAYOUT_P3)
         return fail(PNGPD_ERR_INVALID, "unknown layout %d", layout);
-    if (precision != PNGPD_FP32 && precision != PNGPD_BF16)
+    if (precision != PNGPD_FP32 && precision != PNGPD_BF16 && precision != PNGPD_BF16X3)
         return fail(PNGPD_ERR_INVALID, "unknown precision %d", precision);
     if (!workspace_dev || workspace_bytes < pngpd_forward_workspace_bytes(m, B))
         return fail(PNGPD_ERR_WORKSPACE, "workspace of %zu bytes is smaller than the %zu needed for B=%d",
@@ -337,7 +344,8 @@ static int forward_impl(const pngpd_model* m, const float* x_dev, int layout, in
         return fail(PNGPD_ERR_STATE, "model lives on device %d but device %d is current", m->device, dev);
     hipStream_t s = (hipStream_t)stream;
     Workspace ws(workspace_dev, B);
-    auto launch_stack = precision == PNGPD_BF16 ? pngpd::launch_conv_stack_bf16 : pngpd::launch_conv_stack_f32;
+    auto launch_stack = precision == PNGPD_BF16 ? pngpd::launch_conv_stack_bf16
+                        : precision == PNGPD_BF16X3 ? pngpd::launch_conv_stack_x3 : pngpd::launch_conv_stack_f32;
 
     // STN3d: conv stack (ReLU after the max), then the 1024-512-256-9 regressor + identity
     float* trans = trans_dev ? trans_dev : ws.trans;

@@ -23,28 +23,16 @@
 // f32 path:  one workgroup per candidate, W3 streamed through LDS, v_mfma_f32_32x32x2_f32.
 #include <hip/hip_runtime.h>
 
+#include "conv_stack_common.h"
 #include "kernels.h"
 #include "pngpd.h"
 
 namespace pngpd {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int WAVES = 4;
 constexpr int THREADS = WAVES * 64;
 
-// One wave-instruction of LDS-DMA: 64 lanes x 16 B, LDS destination = lds_piece + lane*16.
-__device__ __forceinline__ void dma_piece(const char* gsrc_piece, char* lds_piece, int lane) {
-    __builtin_amdgcn_global_load_lds((const void*)(gsrc_piece + lane * 16), (lds_void*)lds_piece,
-                                     16, 0, 0);
-}
-
-__device__ __forceinline__ float max3(float a, float b, float c) {
-    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
-}
 
 __device__ __forceinline__ float max16(const f32x16& v) {
     float m0 = max3(v[0], v[1], v[2]);
@@ -153,38 +141,6 @@ constexpr int WS_OFF_W1B = WS_OFF_B2 + C2 * 4;             // BN-folded conv1 ta
 constexpr int WS_OFF_W1 = WS_OFF_W1B + C1 * 16;            // layer-1 A fragments of two candidates (2 x W1F_BYTES)
 constexpr int WS_OFF_B3 = WS_OFF_W1 + 2 * 4096;            // conv3 bias: read once per candidate by every wave
 constexpr int WS_LDS_BYTES = WS_OFF_B3 + C3 * 4;
-typedef f32x4 f32x4v;
-
-// Orders this wave's own LDS accesses (a wave-private table is written, later read, by one wave).
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// relu + bf16 pack of 8 accumulator values.  Rounding keeps the sign, so the clamp can follow the
-// rounding, where it is a packed int16 max against 0; the conversions are written two at a time
-// so that each is one v_cvt_pk_bf16_f32 (8 values: 4 conversions + 4 packed max).
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) short s16x2;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-
-__device__ __forceinline__ unsigned int relu_pack2(float a, float b) {
-    const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
-    s16x2 v = __builtin_bit_cast(s16x2, h);
-    v = __builtin_elementwise_max(v, (s16x2)(0));
-    return __builtin_bit_cast(unsigned int, v);
-}
-
-__device__ __forceinline__ bf16x8 relu_pack(const f32x4v& lo, const f32x4v& hi) {
-    u32x4 r;
-    r[0] = relu_pack2(lo[0], lo[1]);
-    r[1] = relu_pack2(lo[2], lo[3]);
-    r[2] = relu_pack2(hi[0], hi[1]);
-    r[3] = relu_pack2(hi[2], hi[3]);
-    return __builtin_bit_cast(bf16x8, r);
-}
 
 // Layer 1 (3 -> 64, K = 3 plus the bias) also runs on the matrix pipe, as ONE v_mfma_f32_16x16x32_bf16 per tile of
 // 16 channels x 16 points, at float32 accuracy: every float is cut into three bf16 pieces by truncation,
@@ -202,65 +158,9 @@ __device__ __forceinline__ bf16x8 relu_pack(const f32x4v& lo, const f32x4v& hi) 
 // cannot fill it - is shorter: +1.9 % candidates/s in a one-box A/B.
 // The rows of an A tile are a permutation of the channels chosen so that the accumulators of tiles (s, 0) and
 // (s, 1) are, after ReLU and packing, lane (c, q)'s eight k slots 32s + 8q .. + 7 of layer 2's B operand.
-constexpr int W1F_BYTES = 4 * 64 * 16;            // [tile 2s+hl][q][row] x 16 B: the A fragments of one candidate
 static_assert(WS_OFF_B3 - WS_OFF_W1 == 2 * W1F_BYTES, "LDS room for two layer-1 tables");
 
-__device__ __forceinline__ unsigned int f2u(float v) { return __builtin_bit_cast(unsigned int, v); }
-__device__ __forceinline__ float u2f(unsigned int v) { return __builtin_bit_cast(float, v); }
 
-// bf16 bit patterns (upper halves) of the three pieces of v
-__device__ __forceinline__ void split3(float v, unsigned int& h, unsigned int& m, unsigned int& l) {
-    h = f2u(v) & 0xffff0000u;
-    const float r1 = v - u2f(h);
-    m = f2u(r1) & 0xffff0000u;
-    l = f2u(r1 - u2f(m));                      // at most 8 significant bits are left: exact as bf16
-}
-
-// Coordinate q of point c of the two tiles a wave produces next (lanes with q = 3 hold 0).
-struct TilePoints {
-    float x[2];
-};
-
-__device__ __forceinline__ void load_tile_points(const ConvStackArgs& a, int b, int tile0, int c, int q, TilePoints& p) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        int pt = (tile0 + u) * 16 + c;
-        pt = pt < a.P ? pt : a.P - 1;
-        const size_t at = a.layout == PNGPD_LAYOUT_C3P ? ((size_t)b * 3 + q) * a.P + pt : ((size_t)b * a.P + pt) * 3 + q;
-        p.x[u] = q < 3 ? a.x[at] : 0.f;
-    }
-}
-
-// The layer-1 A fragments of candidate b (model/pointnet.py:138-142: the 3x3 input transform is applied to the
-// points before conv1; here it is applied to conv1's weights).  One wave; lane = channel.
-__device__ __forceinline__ void fold_w1_frags(const ConvStackArgs& a, int b, const float4* s_w1base, char* tab, int lane) {
-    float4 w = s_w1base[lane];
-    if (a.trans != nullptr) {
-        const float* T = a.trans + (size_t)b * 9;
-        float4 f;
-        f.x = w.x * T[0] + w.y * T[1] + w.z * T[2];
-        f.y = w.x * T[3] + w.y * T[4] + w.z * T[5];
-        f.z = w.x * T[6] + w.y * T[7] + w.z * T[8];
-        f.w = w.w;
-        w = f;
-    }
-    // channel 32s + 8q' + 4hl + i is row 4q' + i of tile 2s + hl
-    const int t = 2 * (lane >> 5) + ((lane >> 2) & 1), r = 4 * ((lane & 31) >> 3) + (lane & 3);
-    unsigned int bh, bm, bl;
-    split3(w.w, bh, bm, bl);
-    const float comp[3] = {w.x, w.y, w.z};
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        unsigned int h, m, l;
-        split3(comp[d], h, m, l);
-        u32x4 v;
-        v[0] = (h >> 16) | m;                  // slots 0, 1: wh, wm
-        v[1] = (h >> 16) | l;                  //       2, 3: wh, wl
-        v[2] = (m >> 16) | h;                  //       4, 5: wm, wh
-        v[3] = d == 0 ? ((bh >> 16) | bm) : d == 1 ? (bl >> 16) : 0u;
-        *(u32x4*)(tab + ((t * 4 + d) * 16 + r) * 16) = v;
-    }
-}
 
 // Layers 1-2 of two tiles of 16 points; their layer-3 A fragments go to dst, dst + 4 KiB.
 // The LDS reads are issued in groups ahead of their use (layer 2 double-buffers one k-step of
@@ -716,16 +616,13 @@ hipError_t launch_conv_stack_bf16(const ConvStackArgs& a, hipStream_t s) {
     hipError_t e = check_args(a);
     if (e != hipSuccess) return e;
     static_assert(WS_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
-    int dev = 0, n_cu = 0;
-    e = hipGetDevice(&dev);
+    int n_cu = 0;
+    e = device_cu_count(&n_cu);
     if (e != hipSuccess) return e;
-    e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return e;
-    if (n_cu < 1) return hipErrorInvalidDevice;
     // persistent: one workgroup per CU, each strides over the candidates; a batch of fewer candidates than half
     // the CUs is cut into channel pieces (2 or 4 workgroups per candidate)
     auto launch = [&](auto kern, int pieces) {
-        hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+        hipError_t er = set_max_lds_once((const void*)kern, WS_LDS_BYTES);
         if (er != hipSuccess) return er;
         const int per_piece = n_cu / pieces > 0 ? n_cu / pieces : 1;
         hipLaunchKernelGGL(kern, dim3(a.B < per_piece ? a.B : per_piece, pieces), dim3(WS_THREADS), WS_LDS_BYTES, s, a);
@@ -741,12 +638,10 @@ hipError_t launch_conv_stack_f32(const ConvStackArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     static_assert(F32_LDS_BYTES <= 80 * 1024, "two workgroups per CU");
     auto kern = conv_stack_f32_kernel<2>;
-    e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES);
+    e = set_max_lds_once((const void*)kern, F32_LDS_BYTES);
     if (e != hipSuccess) return e;
-    int dev = 0, n_cu = 0;
-    e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    int n_cu = 0;
+    e = device_cu_count(&n_cu);
     if (e != hipSuccess) return e;
     // cut the 32 channel tiles of a candidate into pieces until there is a workgroup for every CU (measured at
     // B = 16 / 64: 187 / 329 us per forward against 231 / 366 us with two workgroups per CU; 860 us uncut)

@@ -39,10 +39,18 @@ struct ConvStackArgs {
     const float* b3;       // [1024] BN-folded conv3 bias
     float* pooled;         // [B,1024] max over points (+bias, optional ReLU)
     int relu_out;          // 1: ReLU after the max (STN), 0: none (trunk)
+    const void* w2lo = nullptr;   // bf16x3 only: second bf16 piece of the conv2 / conv3 weights, same fragment order
+    const void* w3lo = nullptr;
 };
 
 hipError_t launch_conv_stack_bf16(const ConvStackArgs& a, hipStream_t s);
 hipError_t launch_conv_stack_f32(const ConvStackArgs& a, hipStream_t s);
+hipError_t launch_conv_stack_x3(const ConvStackArgs& a, hipStream_t s);
+
+// launch_util.cpp: compute units of the current device; hipFuncAttributeMaxDynamicSharedMemorySize set once per
+// (kernel, device) - both were three runtime calls on every launch
+hipError_t device_cu_count(int* n_cu);
+hipError_t set_max_lds_once(const void* kern, int bytes);
 
 // Y[M,N] = act(X[M,K] * W[N,K]^T + b[N]); fp32 MFMA.  N % 64 == 0, K % 32 == 0.
 // split-k products of the training step's FC layers (few rows): slices * tiles <= SPLITK_MAX_WORKGROUPS, so the

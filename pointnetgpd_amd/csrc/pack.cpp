@@ -76,22 +76,30 @@ void pack_stack(const std::vector<float>& W1f, const std::vector<float>& b1f,
     // conv2 is computed transposed (A = weights): row tile T covers channels 16T..16T+15.
     out.b2 = b2f;
     out.w2_bf16.resize((size_t)C2 * C1);
+    out.w2_lo.resize((size_t)C2 * C1);
     for (int T = 0; T < 8; ++T)
         for (int s = 0; s < 2; ++s)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
                     const int ch2 = 16 * T + (l & 15), k = 32 * s + 8 * (l >> 4) + j;
-                    out.w2_bf16[(((size_t)T * 2 + s) * 64 + l) * 8 + j] = f32_to_bf16_rne(W2f[(size_t)ch2 * C1 + k]);
+                    const float w = W2f[(size_t)ch2 * C1 + k];
+                    const uint16_t hi = f32_to_bf16_rne(w);
+                    out.w2_bf16[(((size_t)T * 2 + s) * 64 + l) * 8 + j] = hi;
+                    out.w2_lo[(((size_t)T * 2 + s) * 64 + l) * 8 + j] = f32_to_bf16_rne(w - bf16_to_f32(hi));
                 }
     // conv3's k slot (quarter q, elem j) of step ks is register j&3 of conv2 row tile 2ks + (j>>2)
     out.w3_bf16.resize((size_t)C3 * C2);
+    out.w3_lo.resize((size_t)C3 * C2);
     for (int NT = 0; NT < 64; ++NT)
         for (int ks = 0; ks < 4; ++ks)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
                     const int ch3 = 16 * NT + (l & 15);
                     const int ch2 = 16 * (2 * ks + (j >> 2)) + 4 * (l >> 4) + (j & 3);
-                    out.w3_bf16[(((size_t)NT * 4 + ks) * 64 + l) * 8 + j] = f32_to_bf16_rne(W3f[(size_t)ch3 * C2 + ch2]);
+                    const float w = W3f[(size_t)ch3 * C2 + ch2];
+                    const uint16_t hi = f32_to_bf16_rne(w);
+                    out.w3_bf16[(((size_t)NT * 4 + ks) * 64 + l) * 8 + j] = hi;
+                    out.w3_lo[(((size_t)NT * 4 + ks) * 64 + l) * 8 + j] = f32_to_bf16_rne(w - bf16_to_f32(hi));
                 }
 
     // f32 images: 32x32x2 fragments, one k per lane half; 4 consecutive steps per 16-byte read

@@ -26,6 +26,8 @@ struct PackedStack {
     std::vector<float> b3;         // [1024]
     std::vector<uint16_t> w2_bf16; // [T8][s2][lane64][j8]    16x16x32 fragments
     std::vector<uint16_t> w3_bf16; // [NT64][ks4][lane64][j8]
+    std::vector<uint16_t> w2_lo;   // bf16(w - w2_bf16), same order: the second piece of the split-bf16 mode
+    std::vector<uint16_t> w3_lo;   // bf16(w - w3_bf16), same order
     std::vector<float> w2_f32;     // [t4][q8][lane64][e4]
     std::vector<float> w3_f32;     // [nt32][q16][lane64][e4]
 };
