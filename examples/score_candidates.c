@@ -83,6 +83,6 @@ int main(int argc, char** argv) {
     if (!f || fwrite(out, sizeof(float), (size_t)B * (k + 9), f) != (size_t)B * (k + 9)) return 1;
     fclose(f);
     CHECK_PNGPD(pngpd_model_destroy(m));
-    printf("scored %d candidates of %d points (%s)\n", B, P, precision == PNGPD_BF16 ? "bf16" : "fp32");
+    printf("scored %d candidates of %d points (%s)\n", B, P, precision == PNGPD_BF16 ? "bf16" : precision == PNGPD_BF16X3 ? "bf16x3" : "fp32");
     return 0;
 }

@@ -28,6 +28,10 @@
 
 namespace pngpd {
 
+#ifndef X3_PRIO_PRODUCE
+#define X3_PRIO_PRODUCE 0
+#define X3_PRIO_CONSUME 3
+#endif
 constexpr int X3_WAVES = 8;
 constexpr int X3_THREADS = X3_WAVES * 64;
 constexpr int X3_PLANE_BYTES = 4096;                       // [ks4][lane64][16 B]
@@ -42,10 +46,17 @@ constexpr int X3_OFF_B3 = X3_OFF_W1 + 2 * W1F_BYTES;       // conv3 bias
 constexpr int X3_LDS_BYTES = X3_OFF_B3 + C3 * 4;
 static_assert(X3_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
+// max(v, 0) as a signed-integer maximum of the bit pattern: one instruction (a float maximum canonicalises its
+// operands first); negative zero and negative NaNs become +0.
+__device__ __forceinline__ float relu_bits(float v) {
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+
 // relu, then the two bf16 pieces of each value, packed in pairs (element 0 in the low half).
 __device__ __forceinline__ void relu_split2(float a, float b, unsigned int& hi, unsigned int& lo) {
-    a = __builtin_fmaxf(a, 0.f);
-    b = __builtin_fmaxf(b, 0.f);
+    a = relu_bits(a);
+    b = relu_bits(b);
     hi = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{a, b}, bf16x2));
     const float ra = a - u2f(hi << 16), rb = b - u2f(hi & 0xffff0000u);      // exact
     lo = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
@@ -81,15 +92,30 @@ __device__ __forceinline__ void load_w2_pair(X3W2& f, int ks, const char* img, i
         for (int s = 0; s < 2; ++s) f.w[tt][s] = *(const bf16x8*)(img + (((2 * ks + tt) * 2 + s) * 64 + lane) * 16);
 }
 
+// The same fragments from memory, as buffer loads: scalar resource + one 32-bit lane offset + a constant, so that the
+// sixteen loads of a produce step share one address register (as flat loads the compiler keeps sixteen 64-bit
+// addresses alive across the whole kernel).
+__device__ __forceinline__ void load_w2_pair_global(X3W2& f, int ks, __amdgpu_buffer_rsrc_t img, unsigned int lane16) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            f.w[tt][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(img, lane16, ((2 * ks + tt) * 2 + s) * 1024, 0));
+}
+#ifdef X3_ABL_W2LO_LDS   // timing only: the lo image read from where the hi image lies
+#define load_w2_pair_global(f, ks, img, lane16) load_w2_pair(f, ks, s_w2h, lane)
+#endif
+
 // Layers 1-2 of one tile of 16 points; the two planes of its layer-3 A fragments go to dst, dst + X3_PLANE_BYTES.
 __device__ __forceinline__ void produce_tile_x3(float px, const char* s_w1f, unsigned int ones, const char* s_w2h,
-                                                const char* g_w2l, const float* s_b2, char* dst, int lane) {
+                                                __amdgpu_buffer_rsrc_t g_w2l, const float* s_b2, char* dst, int lane) {
     const int q = lane >> 4;
     bf16x8 w1f[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) w1f[t] = *(const bf16x8*)(s_w1f + (t * 64 + lane) * 16);
     X3W2 lo_a, lo_b;
-    load_w2_pair(lo_a, 0, g_w2l, lane);
+    const unsigned int lane16 = (unsigned int)lane * 16u;
+    load_w2_pair_global(lo_a, 0, g_w2l, lane16);
     // layer 1: the lane's eight k slots are made from one coordinate of its point (conv_stack.hip)
     bf16x8 xb;
     {
@@ -117,7 +143,7 @@ __device__ __forceinline__ void produce_tile_x3(float px, const char* s_w1f, uns
     for (int ks = 0; ks < 4; ++ks) {
         X3W2& lo_cur = (ks & 1) ? lo_b : lo_a;
         X3W2& lo_nxt = (ks & 1) ? lo_a : lo_b;
-        if (ks + 1 < 4) load_w2_pair(lo_nxt, ks + 1, g_w2l, lane);
+        if (ks + 1 < 4) load_w2_pair_global(lo_nxt, ks + 1, g_w2l, lane16);
         X3W2 hi;
         load_w2_pair(hi, ks, s_w2h, lane);
         f32x4v acc[2];
@@ -184,6 +210,22 @@ __device__ __forceinline__ void consume_tile_x3(const X3AFrag& f, const bf16x8 (
     carry = accA;
 }
 
+// Diagnostic build only (-DPNGPD_STAMPS, tools/diag): shader-clock stamps of workgroup 0 go to a buffer of their own;
+// no output value depends on them.  The product build compiles none of it.
+#ifdef PNGPD_STAMPS
+constexpr int X3_STAMP_FIRST = 7, X3_STAMP_BATCHES = 6, X3_STAMP_EVENTS = 5;
+__device__ unsigned long long g_stamps_x3[X3_WAVES][X3_STAMP_BATCHES * X3_STAMP_EVENTS];
+__device__ unsigned long long g_stamp_clock_x3[4];
+#define X3_STAMP(g, ev)                                                                                   \
+    do {                                                                                                  \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (g) >= X3_STAMP_FIRST &&                    \
+            (g) < X3_STAMP_FIRST + X3_STAMP_BATCHES)                                                      \
+            g_stamps_x3[wave][((g)-X3_STAMP_FIRST) * X3_STAMP_EVENTS + (ev)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define X3_STAMP(g, ev)
+#endif
+
 // NT = channel tiles of 16 per wave.  4 is the throughput shape: a workgroup covers 512 channels, grid.y = 2.  A batch
 // too small to give every CU a workgroup runs NT = 2 with grid.y = 4.  The arithmetic of a channel does not depend on
 // the cut, so a candidate's result does not depend on the batch it is scored in.
@@ -191,7 +233,8 @@ template <int NT>
 __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs a) {
     static_assert(NT == 4 || NT == 2, "channel tiles per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: scalar branches and addresses
     const int c = lane & 15, q = lane >> 4;
 
     char* s_a = smem;
@@ -200,7 +243,8 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
     float4* s_w1base = (float4*)(smem + X3_OFF_W1B);
     char* s_w1f = smem + X3_OFF_W1;
     float* s_b3 = (float*)(smem + X3_OFF_B3);
-    const char* g_w2l = (const char*)a.w2lo;
+    // conv2's lo image as a raw buffer (gfx950: 32-bit elements, no swizzle), W2P_BF16_BYTES long
+    const __amdgpu_buffer_rsrc_t g_w2l = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2lo, 0, (int)W2P_BF16_BYTES, 0x00020000);
     const unsigned int ones = q == 0 ? 0x3f803f80u : q == 1 ? 0x00003f80u : 0u;
 
     const int ct0 = ((int)blockIdx.y * X3_WAVES + wave) * NT;      // first channel tile of this wave
@@ -255,6 +299,13 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
     produce_step(s_a);
     __syncthreads();
 
+#ifdef PNGPD_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        g_stamp_clock_x3[0] = __builtin_amdgcn_s_memtime();
+        g_stamp_clock_x3[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    int g = 0;
+#endif
     int buf = 0;
     for (int ci = 0; ci < ncand; ++ci) {
         const int b = blockIdx.x + ci * stride;
@@ -266,35 +317,50 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
             const int npairs = (nt_b + 1) >> 1;
             // pair of tiles in front of which this wave's produce step sits: the two waves of a SIMD (w, w + 4) are
             // two pairs apart
+#ifdef X3_STEP_LO
+            const int step0 = min(wave < 4 ? X3_STEP_LO : X3_STEP_HI, npairs - 1);
+#else
             const int step0 = min(wave >> 1, npairs - 1);
+#endif
             const char* cur = s_a + buf * X3_BATCH_BYTES;
             char* nxt = s_a + (buf ^ 1) * X3_BATCH_BYTES;
+            // Software pipeline over the tiles: the fragments of the next tile are in flight during the MFMAs of the
+            // current one.  Behind a produce step the current tile is loaded again, so that no A fragment is live
+            // across the step (it needs the registers).
+            X3_STAMP(g, 0);
             X3AFrag fA, fB;
+            load_afrags_x3(fA, cur, lane);
             f32x4v carry = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             for (int i = 0; i < (nt_b >> 1); ++i) {
                 if (i == step0) {
-                    __builtin_amdgcn_s_setprio(0);
+                    X3_STAMP(g, 1);
+                    __builtin_amdgcn_s_setprio(X3_PRIO_PRODUCE);
                     produce_step(nxt);
-                    __builtin_amdgcn_s_setprio(3);
+                    __builtin_amdgcn_s_setprio(X3_PRIO_CONSUME);
+                    X3_STAMP(g, 2);
+                    load_afrags_x3(fA, cur + (2 * i) * X3_TILE_BYTES, lane);
                 }
-                // the fragments are (re)loaded behind the produce step so that no A fragment is live across it
-                load_afrags_x3(fA, cur + (2 * i) * X3_TILE_BYTES, lane);
                 load_afrags_x3(fB, cur + (2 * i + 1) * X3_TILE_BYTES, lane);
                 consume_tile_x3<NT>(fA, bwh, bwl, carry, rm);
+                load_afrags_x3(fA, cur + min(2 * i + 2, nt_b - 1) * X3_TILE_BYTES, lane);
                 consume_tile_x3<NT>(fB, bwh, bwl, carry, rm);
             }
-            if (nt_b & 1) {
-                const int i = nt_b >> 1;
-                if (i == step0) {
-                    __builtin_amdgcn_s_setprio(0);
+            if (nt_b & 1) {                       // odd tail: fA already holds tile nt_b - 1
+                if ((nt_b >> 1) == step0) {
+                    __builtin_amdgcn_s_setprio(X3_PRIO_PRODUCE);
                     produce_step(nxt);
-                    __builtin_amdgcn_s_setprio(3);
+                    __builtin_amdgcn_s_setprio(X3_PRIO_CONSUME);
+                    load_afrags_x3(fA, cur + (nt_b - 1) * X3_TILE_BYTES, lane);
                 }
-                load_afrags_x3(fA, cur + (2 * i) * X3_TILE_BYTES, lane);
                 consume_tile_x3<NT>(fA, bwh, bwl, carry, rm);
             }
             rm[NT - 1] = max3(rm[NT - 1], max3(carry[0], carry[1], carry[2]), carry[3]);
+            X3_STAMP(g, 3);
             lds_barrier();          // orders the A-fragment buffers only: the point load of the next produce step stays in flight
+            X3_STAMP(g, 4);
+#ifdef PNGPD_STAMPS
+            ++g;
+#endif
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -305,7 +371,21 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
             if (q == 0) a.pooled[(size_t)b * C3 + ch] = m;
         }
     }
+#ifdef PNGPD_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        g_stamp_clock_x3[2] = __builtin_amdgcn_s_memtime();
+        g_stamp_clock_x3[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
+
+#ifdef PNGPD_STAMPS
+extern "C" int pngpd_debug_read_stamps_x3(unsigned long long* stamps, unsigned long long* clock) {
+    hipError_t e = hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_stamps_x3), sizeof(g_stamps_x3));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemcpyFromSymbol(clock, HIP_SYMBOL(g_stamp_clock_x3), sizeof(g_stamp_clock_x3));
+}
+#endif
 
 hipError_t launch_conv_stack_x3(const ConvStackArgs& a, hipStream_t s) {
     if (a.B < 1 || a.P < 1 || !a.x || !a.w1tab || !a.w2p || !a.w2lo || !a.b2p || !a.w3p || !a.w3lo || !a.b3 || !a.pooled)

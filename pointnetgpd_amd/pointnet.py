@@ -20,7 +20,11 @@ import torch.nn as nn
 
 from . import _lib
 
-_DEFAULT_PRECISION = os.environ.get("PNGPD_PRECISION", "fp32")
+# Arithmetic of the two conv stacks in eval mode (include/pngpd.h): "fp32" = exact-f32 MFMA, "bf16x3" = split-bf16
+# operands at float32 grade (1e-4 on the log-probabilities whatever their magnitude, about four times the fp32
+# mode's throughput), "bf16" = plain bf16 operands (about three times faster again; its error is 0.4 % of the class
+# scores, i.e. 2e-2 only while they differ by a few units).  The default is the fastest mode that holds 1e-4.
+_DEFAULT_PRECISION = os.environ.get("PNGPD_PRECISION", "bf16x3")
 
 # Bumped whenever library kernels change parameters or running statistics behind torch's back
 # (training step, fused Adam): torch's per-tensor version counters do not see those writes.
@@ -69,7 +73,7 @@ class _HipBacked(nn.Module):
     """Shared plumbing: weight-table assembly, repack-on-change, launch."""
 
     _PARTS = 0
-    precision = _DEFAULT_PRECISION  # "fp32" (exact-f32 MFMA) or "bf16"; instance attribute overrides
+    precision = _DEFAULT_PRECISION  # "fp32", "bf16x3" or "bf16"; an instance attribute overrides
 
     # unit name (C ABI order) -> (layer, batchnorm or None); filled by subclasses
     def _units(self) -> dict:

@@ -87,7 +87,7 @@ def main(argv=None):
     ap.add_argument("--using_mp", action="store_true", default=False)
     ap.add_argument("--model_type", type=str)
     ap.add_argument("--points", type=str, default=None)
-    ap.add_argument("--precision", default=None, choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "bf16"])
     args = ap.parse_args(argv)
     by_type = {"500": "./data/1v_500_2class_ourway2sample.model", "750": "./data/1v_750_2class_ourway2sample.model",
                "3class": "./data/pointgpd_3class.model"}

@@ -24,7 +24,7 @@ PREFIX = {"stn_conv1": ("feat.stn.conv1", "feat.stn.bn1"), "stn_conv2": ("feat.s
           "feat_conv3": ("feat.conv3", "feat.bn3"), "fc1": ("fc1", "bn1"), "fc2": ("fc2", "bn2"), "fc3": ("fc3", None)}
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_c_program_matches_python_modules(tmp_path, precision):
     assert os.path.exists(EXE), "examples/score_candidates missing: run python -c 'import __graft_entry__ as g; g.build()'"
     P, k, B, seed = 750, 2, 37, 51

@@ -1,9 +1,9 @@
 """GPU parity of the HIP forward path (through the C ABI) against the reference's golden vectors
 and against the CPU oracle on fresh seeded inputs.
 
-Tolerances: exact-f32 MFMA path 1e-4 absolute on log-probabilities and on the 3x3 transform;
-bf16 path 2e-2 absolute on log-probabilities; arg-max agreement on candidates whose two best
-classes are further apart than the tolerance.
+Tolerances: exact-f32 MFMA path and split-bf16 path ("bf16x3": hi + lo operands, three bf16 MFMAs per product)
+1e-4 absolute on log-probabilities and on the 3x3 transform; plain bf16 path 2e-2 absolute on log-probabilities;
+arg-max agreement on candidates whose two best classes are further apart than the tolerance.
 """
 import glob
 import os
@@ -23,6 +23,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 EVAL_FILES = sorted(glob.glob(os.path.join(GOLDEN, "eval_*.npz")))
 FP32_ATOL = 1e-4
 BF16_ATOL = 2e-2
+X3_ATOL = 1e-4          # operands exact to 2^-18: measured 6e-6 .. 2.1e-5 on the golden files
+F32_GRADE = [("fp32", FP32_ATOL), ("bf16x3", X3_ATOL)]
+ALL_MODES = F32_GRADE + [("bf16", BF16_ATOL)]
 
 
 def hip_model(P, k, seed, scale, precision, gain=2.0):
@@ -39,23 +42,24 @@ def top1_agree(logp, ref_logp, tol):
     return (logp.argmax(1) == ref_logp.argmax(1))[decided].all(), int(decided.sum())
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("path", EVAL_FILES, ids=[os.path.basename(p)[5:-4] for p in EVAL_FILES])
-def test_fp32_matches_reference_golden(path):
+def test_fp32_matches_reference_golden(path, precision):
     d = np.load(path)
     P, k, seed, B = (int(v) for v in d["meta"])
-    m = hip_model(P, k, seed, float(d["input_scale"]), "fp32", float(d["gain"]))
+    m = hip_model(P, k, seed, float(d["input_scale"]), precision, float(d["gain"]))
     x = torch.from_numpy(synth.candidate_points(seed, B, P, str(d["kind"]))).cuda()
     logp, trans = m(x)
     feat, trans2 = m.feat(x)
     stn_trans = m.feat.stn(x)
     torch.cuda.synchronize()
     err = np.abs(logp.cpu().numpy() - d["logp"]).max()
-    print(f"fp32 max |dlogp| = {err:.3e}")
+    print(f"{precision} max |dlogp| = {err:.3e}")
     assert err <= FP32_ATOL
     np.testing.assert_allclose(trans.cpu().numpy(), d["trans"], rtol=0, atol=FP32_ATOL)
     np.testing.assert_allclose(trans2.cpu().numpy(), d["trans"], rtol=0, atol=FP32_ATOL)
     np.testing.assert_allclose(stn_trans.cpu().numpy(), d["trans"], rtol=0, atol=FP32_ATOL)
-    np.testing.assert_allclose(feat.cpu().numpy(), d["feat"], rtol=2e-5, atol=FP32_ATOL)
+    np.testing.assert_allclose(feat.cpu().numpy(), d["feat"], rtol=2e-5 if precision == "fp32" else 1e-4, atol=FP32_ATOL)
     ok, n = top1_agree(logp.cpu().numpy(), d["logp"], FP32_ATOL)
     assert ok and n > 0
 
@@ -76,7 +80,7 @@ def test_bf16_matches_reference_golden(path):
 
 
 @pytest.mark.parametrize("B", [1, 3, 64])
-@pytest.mark.parametrize("precision,tol", [("fp32", FP32_ATOL), ("bf16", BF16_ATOL)])
+@pytest.mark.parametrize("precision,tol", ALL_MODES)
 def test_against_oracle_fresh_inputs(B, precision, tol):
     P, k, seed = 750, 2, 31
     sd = synth.torch_state_dict(seed, k, 0.02)
@@ -89,20 +93,21 @@ def test_against_oracle_fresh_inputs(B, precision, tol):
     err = (logp.cpu() - ref_logp).abs().max().item()
     print(f"{precision} B={B}: max |dlogp| = {err:.3e}")
     assert err <= tol
-    assert (trans.cpu() - ref_trans).abs().max().item() <= (tol if precision == "fp32" else 5e-2)
+    assert (trans.cpu() - ref_trans).abs().max().item() <= (tol if precision != "bf16" else 5e-2)
     ok, _ = top1_agree(logp.cpu().numpy(), ref_logp.numpy(), tol)
     assert ok
 
 
-RAGGED = [(1, 1), (2, 2500), (2, 15), (3, 16), (3, 17), (5, 255), (5, 256), (5, 257), (4, 513), (257, 48), (300, 300), (600, 33)]
+RAGGED = [(1, 1), (2, 2500), (2, 15), (3, 16), (3, 17), (5, 127), (5, 128), (5, 129), (5, 255), (5, 256), (5, 257), (4, 513),
+          (63, 40), (64, 40), (65, 40), (128, 33), (129, 33), (257, 48), (300, 300), (600, 33)]
 
 
 @pytest.mark.parametrize("B,P", RAGGED, ids=[f"B{b}_P{p}" for b, p in RAGGED])
-@pytest.mark.parametrize("precision,tol", [("fp32", FP32_ATOL), ("bf16", BF16_ATOL)])
+@pytest.mark.parametrize("precision,tol", ALL_MODES)
 def test_ragged_sizes(B, P, precision, tol):
     """Point counts around the 16-point tile and 256-point batch edges (padding = duplicates of the
     last point) and candidate counts around the number of CUs (the bf16 kernel is persistent: one
-    workgroup per CU strides over the candidates)."""
+    workgroup per CU strides over the candidates; bf16x3: two workgroups per candidate, batches of 128 points)."""
     k, seed = 2, 41
     sd = synth.torch_state_dict(seed, k, 0.02)
     oracle = po.build_cls(P, k, sd)
@@ -113,11 +118,12 @@ def test_ragged_sizes(B, P, precision, tol):
     logp, trans = m(x.cuda())
     err = (logp.cpu() - ref_logp).abs().max().item()
     assert err <= tol, err
-    assert (trans.cpu() - ref_trans).abs().max().item() <= (tol if precision == "fp32" else 5e-2)
+    assert (trans.cpu() - ref_trans).abs().max().item() <= (tol if precision != "bf16" else 5e-2)
 
 
-def test_points_layout_is_bitwise_equivalent():
-    m = hip_model(750, 2, 33, 1.0, "bf16", 1.7)
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_points_layout_is_bitwise_equivalent(precision):
+    m = hip_model(750, 2, 33, 1.0, precision, 1.7)
     x = torch.from_numpy(synth.candidate_points(33, 5, 750, "normal")).cuda()
     a, ta = m(x)
     b, tb = m.forward_points(x.transpose(1, 2).contiguous())
@@ -155,9 +161,9 @@ def test_weights_repacked_after_in_place_update():
     assert not torch.equal(a, b)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_full_size_properties(precision):
-    """B=4096, P=750 in both arithmetic modes: results do not depend on batch position, batch size or
+    """B=4096, P=750 in every arithmetic mode: results do not depend on batch position, batch size or
     on the order of the points inside a candidate (the max-pool is symmetric) - bit for bit."""
     B = 4096
     P, seed = 750, 41
@@ -176,7 +182,7 @@ def test_full_size_properties(precision):
     oracle = po.build_cls(P, 2, synth.torch_state_dict(seed, 2, 0.02))
     with torch.no_grad():
         ref, _ = oracle(x[idx].cpu())
-    tol = FP32_ATOL if precision == "fp32" else BF16_ATOL
+    tol = BF16_ATOL if precision == "bf16" else FP32_ATOL
     assert (logp[idx].cpu() - ref).abs().max().item() <= tol
 
 
@@ -227,7 +233,7 @@ def test_p1000_full_view_variant():
     x = torch.from_numpy(synth.candidate_points(seed, 3, P, "normal"))
     with torch.no_grad():
         ref, _ = po.build_cls(P, 2, sd)(x)
-    for precision, tol in (("fp32", FP32_ATOL), ("bf16", BF16_ATOL)):
+    for precision, tol in ALL_MODES:
         m = PointNetCls(P, 3, 2)
         m.load_state_dict(sd)
         m = m.cuda().eval()
@@ -240,7 +246,9 @@ def test_bf16_error_against_logit_magnitude():
     """The 2e-2 absolute bar of the bf16 path is met on networks whose class scores differ by a few units; the error
     itself is proportional to the scores (bf16 rounds h1, h2 and the weights to 2^-9 relative).  Networks of growing
     weight gain show it: the error stays below 1 % of the largest score difference at every gain, the absolute bar
-    fails beyond a score difference of about 5, and the exact-f32 mode holds its 1e-4 relative to the same scale."""
+    fails beyond a score difference of about 5, and the exact-f32 mode holds its 1e-4 relative to the same scale.
+    The split-bf16 mode (operands exact to 2^-18) stays within 4e-5 of the score difference, so it meets the 2e-2 absolute
+    bar up to differences of several hundred (asserted at 77) and 1e-4 where plain bf16 meets 2e-2."""
     P, k, seed, B = 750, 2, 47, 64
     x = torch.from_numpy(synth.candidate_points(seed, B, P, "gripper"))
     rows = []
@@ -250,16 +258,20 @@ def test_bf16_error_against_logit_magnitude():
             ref = po.build_cls(P, k, sd)(x)[0].double()
         spread = (ref.max(1).values - ref.min(1).values).max().item()       # = largest |logit_0 - logit_1|
         errs = {}
-        for precision in ("bf16", "fp32"):
+        for precision in ("bf16", "fp32", "bf16x3"):
             logp = hip_model(P, k, seed, 0.02, precision, gain)(x.cuda())[0].cpu().double()
             errs[precision] = (logp - ref).abs().max().item()
-        rows.append((gain, spread, errs["bf16"], errs["fp32"]))
+        rows.append((gain, spread, errs["bf16"], errs["fp32"], errs["bf16x3"]))
         print(f"gain {gain}: largest score difference {spread:8.3f}  bf16 err {errs['bf16']:.3e} "
-              f"({100 * errs['bf16'] / max(spread, 1.0):.2f} %)  fp32 err {errs['fp32']:.3e}")
-    for gain, spread, e16, e32 in rows:
+              f"({100 * errs['bf16'] / max(spread, 1.0):.2f} %)  fp32 err {errs['fp32']:.3e}  bf16x3 err {errs['bf16x3']:.3e}")
+    for gain, spread, e16, e32, ex3 in rows:
         assert e16 <= 0.01 * max(spread, 2.0), (gain, spread, e16)
         assert e32 <= 1e-4 * max(1.0, spread / 5.0), (gain, spread, e32)
+        assert ex3 <= max(1e-4, 4e-5 * spread), (gain, spread, ex3)
+        if spread <= 500.0:
+            assert ex3 <= BF16_ATOL, (gain, spread, ex3)
     assert rows[-1][1] > 5.0            # the sweep does reach scores where the absolute bar no longer applies
+    assert any(77.0 <= r[1] <= 500.0 for r in rows)     # and one where only the float32-grade modes hold 2e-2
 
 
 def test_main_test_command_line(tmp_path, capsys):

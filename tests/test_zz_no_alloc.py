@@ -21,7 +21,7 @@ def _outputs(B, k):
             torch.full((B, 1024), float("nan"), device="cuda"))
 
 
-@pytest.mark.parametrize("precision", [_lib.FP32, _lib.BF16])
+@pytest.mark.parametrize("precision", [_lib.FP32, _lib.BF16, _lib.BF16X3])
 def test_no_alloc_forward_equals_forward_infer(precision):
     P, k = 750, 2
     m = PointNetCls(P, 3, k)

@@ -20,6 +20,7 @@ def _opt(name, default):
     return default
 
 
+PRECISION = _opt("--precision", "bf16")
 DIAG = os.path.join(ROOT, "tools", "diag", _opt("--lib", "libpngpd_diag") + ".so")
 
 
@@ -50,7 +51,7 @@ def run(B=4096, P=750):
     model = PointNetCls(P, 3, 2)
     model.load_state_dict(synth.torch_state_dict(0, 2, 0.02), strict=True)
     model = model.to(dev).eval()
-    model.precision = "bf16"
+    model.precision = PRECISION
     x = torch.from_numpy(synth.candidate_points(0, B, P)).to(dev)
     for _ in range(300):
         model(x)
@@ -59,7 +60,8 @@ def run(B=4096, P=750):
     waves, nb, ne = 8, 6, 5
     stamps = (ctypes.c_ulonglong * (waves * nb * ne))()
     clock = (ctypes.c_ulonglong * 4)()
-    rc = lib.pngpd_debug_read_stamps(stamps, clock)
+    lib = ctypes.CDLL(DIAG)
+    rc = (lib.pngpd_debug_read_stamps_x3 if PRECISION == "bf16x3" else lib.pngpd_debug_read_stamps)(stamps, clock)
     assert rc == 0, rc
     s = np.array(stamps, dtype=np.int64).reshape(waves, nb, ne)
     cyc, rt = clock[2] - clock[0], clock[3] - clock[1]
