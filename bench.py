@@ -35,16 +35,20 @@ from pointnetgpd_amd.pointnet import PointNetCls  # noqa: E402
 # algorithmic work, BN folded, 1 MAC = 2 flop (bias / ReLU / max / softmax not counted)
 FLOP_PER_POINT_STACK = 2 * (3 * 64 + 64 * 128 + 128 * 1024)          # 278,912
 FLOP_FC_STN = 2 * (1024 * 512 + 512 * 256 + 256 * 9)
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}                        # dense MFMA peaks, MI355X
+# dense MFMA peaks, MI355X.  bf16x3 computes every product as three bf16 piece products, so what the matrix pipe can
+# deliver of such products is the dense bf16 peak / 3 (`achieved` stays algorithmic flops over time).
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": round(2500.0 / 3.0, 1)}
+PEAK_NOTE = {"bf16x3": " (float32-grade products as 3 bf16 piece products; peak = dense bf16 peak / 3)"}
 
 
 def flop_per_candidate(P, k):
     return P * (2 * FLOP_PER_POINT_STACK + 18) + FLOP_FC_STN + 2 * (1024 * 512 + 512 * 256 + 256 * k)
 
 
-def device_points(seed, B, P, rank, device):
+def device_points(seed, B, P, rank, device, first=None):
     """Candidate points generated on the device: uniform in the synthetic gripper box, keyed by
-    (seed, global candidate id) so that the data of a candidate does not depend on the sharding."""
+    (seed, global candidate id) so that the data of a candidate does not depend on the sharding.
+    `first` = global id of this rank's first candidate (default: rank * B)."""
     g = torch.Generator(device=device)
     out = torch.empty((B, 3, P), dtype=torch.float32, device=device)
     hd, ow, hh = synth.GRIPPER_BOX
@@ -52,7 +56,7 @@ def device_points(seed, B, P, rank, device):
     shift = torch.tensor([0.0, -ow / 2, -hh / 2], device=device).view(1, 3, 1)
     chunk = 1024
     for c0 in range(0, B, chunk):
-        g.manual_seed(seed * 1_000_003 + (rank * B + c0))
+        g.manual_seed(seed * 1_000_003 + ((rank * B if first is None else first) + c0))
         n = min(chunk, B - c0)
         out[c0:c0 + n] = torch.rand((n, 3, P), generator=g, device=device) * scale + shift
     return out
@@ -211,7 +215,8 @@ def online_workload(args, dev, rank, n_gpus, dist):
             "config": {"workload": f"scene {S} pts x {G} grasps per GPU, crop+subsample x{R}+PointNetCls P={P}+vote",
                        "crop_ms": round(crop_ms, 3), "score_ms": round(score_ms, 3), "pair_tests_per_s": round(S * G / (crop_ms * 1e-3), 1),
                        "crop_algorithmic_GBps": round(crop_bytes / (crop_ms * 1e-3) / 1e9, 2),
-                       "mean_points_per_grasp": round(total_idx / G, 1), "good_grasps": int(out.order.numel())},
+                       "mean_points_per_grasp": round(total_idx / G, 1), "good_grasps": int(out.order.numel()),
+                       "process_group": group_info(dist)},
             # the crop + subsample stage against the HBM roofline (its main kernel is bound by vector-instruction
             # issue, profiles/r2_crop_stage.md); the stage that dominates the frame is the scoring, whose kernel the
             # score workload reports
@@ -222,7 +227,8 @@ def online_workload(args, dev, rank, n_gpus, dist):
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_online(scene.cpu().numpy(), grasps, limits, P, k, R)
-        print(json.dumps(line), flush=True)
+        return line
+    return None
 
 
 def train_workload(args, dev, rank, n_gpus, dist):
@@ -256,11 +262,17 @@ def train_workload(args, dev, rank, n_gpus, dist):
     # dominant kernel of the step: the fused conv3 product / max / arg-max kernel, timed with HIP events on the
     # launch stream inside 20 further full steps (two launches per step)
     trainer.conv3_ms = []
+    trainer.wait_events = []          # HIP events around the waits for the gradient all-reduces (N > 1 only)
     for _ in range(20):
         trainer.step(x, target)
     torch.cuda.synchronize(dev)
     conv3_ms = sum(trainer.conv3_ms) / len(trainer.conv3_ms)
     trainer.conv3_ms = None
+    # how long the compute stream stood still for the collectives: what of the three bucket all-reduces is NOT hidden
+    # behind the backward kernels (the last bucket, mostly)
+    waits = [a.elapsed_time(b) for a, b in trainer.wait_events]
+    trainer.wait_events = None
+    exposed_ms = max_over_ranks(dist, sum(waits) / len(waits), dev) if waits else None
     if rank == 0:
         conv3_flop = 2.0 * 128 * 1024 * B * P
         conv3_tf = conv3_flop / (conv3_ms * 1e-3) / 1e12
@@ -274,12 +286,15 @@ def train_workload(args, dev, rank, n_gpus, dist):
             "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
             "config": {"workload": f"PointNetCls {k}-class train step, P={P}, batch {B} per GPU, Adam lr 0.005, "
                                    "fp32 gradient all-reduced in three buckets over RCCL",
-                       "loss": round(float(loss.item()), 5), "reference_equivalent_tflops": round(flop * args.steps / elapsed / 1e12, 2)},
+                       "loss": round(float(loss.item()), 5), "reference_equivalent_tflops": round(flop * args.steps / elapsed / 1e12, 2),
+                       "process_group": group_info(dist),
+                       "exposed_allreduce_wait_ms": None if exposed_ms is None else round(exposed_ms, 4)},
             "roofline": _train_roofline(conv3_tf, conv3_ms, conv3_flop, B, P),
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_train(P, k)
-        print(json.dumps(line), flush=True)
+        return line
+    return None
 
 
 def _train_roofline(conv3_tf, conv3_ms, conv3_flop, B, P):
@@ -351,7 +366,186 @@ def voxel_workload(args, dev, rank, n_gpus, dist):
             dt = (time.perf_counter() - t0) / reps
             line["cpu_baseline"] = {"value": round(S / dt, 1), "unit": "points/s", "cores": 1, "kind": "port",
                                     "sample": f"numpy restatement of get_voxel_fun on the same {S} points, n={n}, {reps} calls"}
-        print(json.dumps(line), flush=True)
+        return line
+    return None
+
+
+def per_rank_batch(args, rank, n_gpus):
+    """Candidates this rank scores per step: --batch each (weak scaling), or its contiguous share of --global-batch
+    (strong scaling: the total is fixed, dist.shard_range cuts it)."""
+    if args.global_batch:
+        from pointnetgpd_amd.dist import shard_range
+        lo, hi = shard_range(args.global_batch, rank, n_gpus)
+        return hi - lo
+    return args.batch
+
+
+def group_info(dist):
+    """What the ranks are connected by: backend and rank count of the process group (RCCL = torch's "nccl")."""
+    if dist is None:
+        return {"backend": None, "ranks": 1}
+    return {"backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(), "ranks": dist.get_world_size()}
+
+
+def score_workload(args, dev, rank, n_gpus, dist, B, P, precision, steps, warmup, full):
+    """Batch scoring (configs 2 and 3): `steps` eval forwards of PointNetCls over B candidates per rank that are
+    resident in HBM.  full=False is the short form used for the extra legs of the default run: no PCIe-inclusive
+    rate, no CPU baseline, fewer timed conv-stack launches."""
+    k, seed = args.classes, 0
+    model = PointNetCls(P, 3, k)
+    model.load_state_dict(synth.torch_state_dict(seed, k, 0.02), strict=True)
+    model = model.to(dev).eval()
+    model.precision = precision
+    first = 0
+    if args.global_batch:
+        from pointnetgpd_amd.dist import shard_range
+        first = shard_range(args.global_batch, rank, n_gpus)[0]
+    x = device_points(seed, B, P, rank, dev, first=first if args.global_batch else None)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # The matrix-core clock takes ~30 ms of sustained load to settle after an idle period (launch
+    # durations of one kernel drift by 20 % over the first 40 launches), so a short --warmup is
+    # topped up to SETTLE_STEPS untimed steps; the timed region is exactly `steps` steps.
+    settle = max(warmup, SETTLE_STEPS) if full else warmup
+    for _ in range(settle):
+        model(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        logp, trans = model(x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(dist, elapsed, dev)
+    assert torch.isfinite(logp).all()
+
+    pcie_rate = None
+    if full:
+        # the same step when the candidates start in (pinned) host memory: one H2D copy of x per step, not
+        # overlapped with compute.  Reported beside the headline, never as `value`.
+        x_host = x.cpu().pin_memory()
+        for _ in range(5):
+            x.copy_(x_host, non_blocking=True)
+            model(x)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        host_steps = 50
+        for _ in range(host_steps):
+            x.copy_(x_host, non_blocking=True)
+            model(x)
+        torch.cuda.synchronize(dev)
+        pcie_rate = B * host_steps / (time.perf_counter() - t1)
+
+    # dominant kernel: the fused conv stack, timed inside full scoring steps: every step brackets its two
+    # conv-stack launches (STN, trunk) with HIP events on the launch stream (pngpd_forward_infer_timed)
+    h = model._handle(dev)
+    ws = h.workspace(B)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    prec = _lib.PRECISIONS[precision]
+    logp_t = torch.empty((B, k), dtype=torch.float32, device=dev)
+    trans_t = torch.empty((B, 9), dtype=torch.float32, device=dev)
+    pair = (ctypes.c_float * 2)()
+    conv_ms = []
+    skip, timed = (10, 50) if full else (3, 10)
+    for i in range(skip + timed):
+        _lib.check(h.lib.pngpd_forward_infer_timed(h.ptr, ctypes.c_void_p(x.data_ptr()), _lib.LAYOUT_C3P, B, P, prec,
+                                                   ctypes.c_void_p(logp_t.data_ptr()), ctypes.c_void_p(trans_t.data_ptr()),
+                                                   None, ctypes.c_void_p(ws.data_ptr()), ws.numel(), pair,
+                                                   ctypes.c_void_p(stream)))
+        if i >= skip:
+            conv_ms += [pair[0], pair[1]]
+    kernel_ms = sum(conv_ms) / len(conv_ms)          # mean duration of one conv-stack launch
+    flop_launch = float(B) * P * FLOP_PER_POINT_STACK
+    achieved = flop_launch / (kernel_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[precision]
+    # HBM bytes per launch of that kernel come from PMC passes (FETCH_SIZE / WRITE_SIZE, corrected for
+    # gfx950) that cannot run inside this process; the committed measurement is reported when it is
+    # for this exact configuration, else null.
+    traffic = None
+    for name in ("r3_conv_stack_traffic.json", "r3_conv_stack_x3_traffic.json", "r2_conv_stack_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if traffic is None and os.path.exists(tpath):
+            t = json.load(open(tpath))
+            if t["config"] == {"B": B, "P": P, "precision": precision}:
+                traffic = t["hbm_bytes_per_launch"]
+    if rank != 0:
+        return None
+    total_per_step = float(args.global_batch) if args.global_batch else float(n_gpus) * B
+    total = total_per_step * steps
+    fc = {"bf16": "split-bf16 (fp32-grade)", "bf16x3": "split-bf16 (fp32-grade)", "fp32": "fp32"}[precision]
+    line = {
+        "metric": f"grasp candidates scored/sec at N={P}",
+        "value": round(total / elapsed, 1),
+        "unit": "candidates/s",
+        "n_gpus": n_gpus,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(1e3 * elapsed / steps, 4),
+        "higher_is_better": True,
+        "scaling": "strong" if args.global_batch else "weak",
+        "vs_baseline": None,
+        "dtype": precision,
+        "data": "synthetic",
+        "config": {"workload": f"PointNetCls {k}-class eval forward, P={P}, batch {B} per GPU"
+                               + (f" (global batch {args.global_batch} cut over {n_gpus} ranks)" if args.global_batch else "")
+                               + f", {precision} fused conv/max-pool kernels + {fc} FC, synthetic weights",
+                   "batch_per_gpu": B, "points": P, "classes": k, "parallelism": f"dp{n_gpus}",
+                   "process_group": group_info(dist),
+                   "untimed_steps_before_timing": settle,
+                   "whole_net_tflops": round(total / elapsed * flop_per_candidate(P, k) / 1e12, 2)},
+        "roofline": {"bound": "mfma", "kernel": f"conv_stack_{precision}" + PEAK_NOTE.get(precision, ""),
+                     "achieved": round(achieved, 2),
+                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                     "kernel_ms": round(kernel_ms, 4), "flop_per_launch": flop_launch},
+    }
+    if pcie_rate is not None:
+        line["config"]["pcie_inclusive_candidates_per_s_per_gpu"] = round(pcie_rate, 1)
+    if full and n_gpus == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(P, k, seed)
+    return line
+
+
+def _brief(line):
+    """What an extra leg contributes to the headline line: its throughput and its dominant kernel's roofline."""
+    if line is None:
+        return None
+    r = line["roofline"]
+    out = {"workload": line["config"]["workload"], "metric": line["metric"], "value": line["value"], "unit": line["unit"],
+           "ms_per_step": line["ms_per_step"], "steps": line["steps"], "warmup": line["warmup"], "dtype": line["dtype"],
+           "scaling": line["scaling"],
+           "roofline": {key: r[key] for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic") if key in r}}
+    for key in ("kernel_ms", "stage_ms"):
+        if key in r:
+            out["roofline"][key] = r[key]
+    for key in ("crop_ms", "score_ms", "loss", "exposed_allreduce_wait_ms"):
+        if key in line["config"]:
+            out[key] = line["config"][key]
+    return out
+
+
+def other_workloads(args, dev, rank, n_gpus, dist):
+    """Short legs of the other configurations, run behind the headline with the same per-GPU sizes on every rank:
+    the split-bf16 and exact-f32 modes of the headline batch, P=500 (config 3's per-GPU share at 8 GPUs), the training
+    step (config 4) and the online frame (config 5).  Each is timed like the headline (barrier + synchronise on both
+    sides, max over ranks); none runs a CPU baseline."""
+    import copy
+    a = copy.copy(args)
+    a.global_batch, a.no_cpu_baseline = 0, True
+    legs = {}
+    legs["score_bf16x3_b4096_p750"] = _brief(score_workload(a, dev, rank, n_gpus, dist, B=4096, P=750, precision="bf16x3",
+                                                            steps=30, warmup=10, full=False))
+    legs["score_fp32_b4096_p750"] = _brief(score_workload(a, dev, rank, n_gpus, dist, B=4096, P=750, precision="fp32",
+                                                          steps=20, warmup=5, full=False))
+    legs["score_bf16_b8192_p500"] = _brief(score_workload(a, dev, rank, n_gpus, dist, B=8192, P=500, precision="bf16",
+                                                          steps=30, warmup=10, full=False))
+    a.points, a.train_batch, a.steps, a.warmup = 750, 256, 30, 15
+    legs["train_b256_p750"] = _brief(train_workload(a, dev, rank, n_gpus, dist))
+    a.scene_points, a.grasps, a.steps, a.warmup, a.precision = 1_000_000, 10_000, 10, 3, "bf16"
+    legs["online_s1m_g10k"] = _brief(online_workload(a, dev, rank, n_gpus, dist))
+    return legs
 
 
 SETTLE_STEPS = 50
@@ -375,8 +569,13 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="candidates per GPU")
     ap.add_argument("--points", type=int, default=750)
     ap.add_argument("--classes", type=int, default=2)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="score workload: only the headline, without the short legs of the other configurations")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="score workload: total candidates per step, cut over the ranks (strong scaling; e.g. "
+                         "--global-batch 65536 --points 500); default: --batch per GPU (weak scaling)")
     ap.add_argument("--workload", default="score", choices=["score", "online", "train", "voxel"],
                     help="score: headline batch scoring; online: 1M-point scene x 10k grasps crop+score; "
                          "train: training step, batch 256 per GPU")
@@ -414,115 +613,21 @@ def main():
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     if args.workload in ("online", "train", "voxel"):
-        {"online": online_workload, "train": train_workload, "voxel": voxel_workload}[args.workload](args, dev, rank, n_gpus, dist)
+        line = {"online": online_workload, "train": train_workload, "voxel": voxel_workload}[args.workload](args, dev, rank, n_gpus, dist)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    B, P, k, seed = args.batch, args.points, args.classes, 0
-    model = PointNetCls(P, 3, k)
-    model.load_state_dict(synth.torch_state_dict(seed, k, 0.02), strict=True)
-    model = model.to(dev).eval()
-    model.precision = args.precision
-    x = device_points(seed, B, P, rank, dev)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    # The matrix-core clock takes ~30 ms of sustained load to settle after an idle period (launch
-    # durations of one kernel drift by 20 % over the first 40 launches), so a short --warmup is
-    # topped up to SETTLE_STEPS untimed steps; the timed region is exactly --steps steps.
-    settle = max(args.warmup, SETTLE_STEPS)
-    for _ in range(settle):
-        model(x)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        logp, trans = model(x)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(dist, elapsed, dev)
-    assert torch.isfinite(logp).all()
-
-    # the same step when the candidates start in (pinned) host memory: one H2D copy of x per step, not
-    # overlapped with compute.  Reported beside the headline, never as `value`.
-    x_host = x.cpu().pin_memory()
-    for _ in range(5):
-        x.copy_(x_host, non_blocking=True)
-        model(x)
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    host_steps = 50
-    for _ in range(host_steps):
-        x.copy_(x_host, non_blocking=True)
-        model(x)
-    torch.cuda.synchronize(dev)
-    pcie_rate = B * host_steps / (time.perf_counter() - t1)
-
-    # dominant kernel: the fused conv stack, timed inside full scoring steps: every step brackets its two
-    # conv-stack launches (STN, trunk) with HIP events on the launch stream (pngpd_forward_infer_timed)
-    h = model._handle(dev)
-    ws = h.workspace(B)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    prec = _lib.PRECISIONS[args.precision]
-    logp_t = torch.empty((B, k), dtype=torch.float32, device=dev)
-    trans_t = torch.empty((B, 9), dtype=torch.float32, device=dev)
-    pair = (ctypes.c_float * 2)()
-    conv_ms = []
-    for i in range(10 + 50):
-        _lib.check(h.lib.pngpd_forward_infer_timed(h.ptr, ctypes.c_void_p(x.data_ptr()), _lib.LAYOUT_C3P, B, P, prec,
-                                                   ctypes.c_void_p(logp_t.data_ptr()), ctypes.c_void_p(trans_t.data_ptr()),
-                                                   None, ctypes.c_void_p(ws.data_ptr()), ws.numel(), pair,
-                                                   ctypes.c_void_p(stream)))
-        if i >= 10:
-            conv_ms += [pair[0], pair[1]]
-
-    class _Ms:      # mean duration of one conv-stack launch
-        value = sum(conv_ms) / len(conv_ms)
-    ms = _Ms()
-    flop_launch = float(B) * P * FLOP_PER_POINT_STACK
-    achieved = flop_launch / (ms.value * 1e-3) / 1e12
-    peak = PEAK_TFLOPS[args.precision]
-    # HBM bytes per launch of that kernel come from PMC passes (FETCH_SIZE / WRITE_SIZE, corrected for
-    # gfx950) that cannot run inside this process; the committed measurement is reported when it is
-    # for this exact configuration, else null.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r2_conv_stack_traffic.json")
-    if os.path.exists(tpath):
-        t = json.load(open(tpath))
-        if t["config"] == {"B": B, "P": P, "precision": args.precision}:
-            traffic = t["hbm_bytes_per_launch"]
-
+    line = score_workload(args, dev, rank, n_gpus, dist, B=per_rank_batch(args, rank, n_gpus), P=args.points,
+                          precision=args.precision, steps=args.steps, warmup=args.warmup, full=True)
+    if not args.no_other_workloads:
+        others = other_workloads(args, dev, rank, n_gpus, dist)
+        if rank == 0:
+            line["config"]["other_workloads"] = others
     if rank == 0:
-        total = float(n_gpus) * B * args.steps
-        line = {
-            "metric": f"grasp candidates scored/sec at N={P}",
-            "value": round(total / elapsed, 1),
-            "unit": "candidates/s",
-            "n_gpus": n_gpus,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.precision,
-            "data": "synthetic",
-            "config": {"workload": f"PointNetCls {k}-class eval forward, P={P}, batch {B} per GPU, "
-                                   f"{args.precision} fused conv/max-pool kernels + "
-                                   f"{'split-bf16 (fp32-grade)' if args.precision == 'bf16' else 'fp32'} FC, synthetic weights",
-                       "batch_per_gpu": B, "points": P, "classes": k, "parallelism": f"dp{n_gpus}",
-                       "untimed_steps_before_timing": settle,
-                       "pcie_inclusive_candidates_per_s_per_gpu": round(pcie_rate, 1), "whole_net_tflops": round(total / elapsed * flop_per_candidate(P, k) / 1e12, 2)},
-            "roofline": {"bound": "mfma", "kernel": f"conv_stack_{args.precision}", "achieved": round(achieved, 2),
-                         "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "kernel_ms": round(ms.value, 4), "flop_per_launch": flop_launch},
-        }
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(P, k, seed)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

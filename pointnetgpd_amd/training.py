@@ -277,6 +277,7 @@ class Trainer:
             self.buckets.append((part, lo, hi))
         self._ws = None
         self.conv3_ms = None      # set to a list to collect the conv3 kernel durations of every step
+        self.wait_events = None   # set to a list to collect (before, after) events around the waits for the collectives
         self.always_bucketed = False   # part-by-part backward and its collectives even on one rank (for tests)
         if self.world_size() > 1:
             self.broadcast_state()
@@ -334,9 +335,16 @@ class Trainer:
         for part, lo, hi in self.buckets:           # head, trunk, transform regressor
             train_backward(model, x, logp, dlogp, None, self._ws, grad_of, parts=part)
             pending.append(self._reduce_bucket(lo, hi))
+        timed = self.wait_events is not None and self._device_collectives()
+        if timed:
+            before, after = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            before.record()
         for work in pending:
             if work is not None:
                 work.wait()                         # the current stream waits for the collective's stream
+        if timed:
+            after.record()
+            self.wait_events.append((before, after))
         return loss, logp
 
     def apply(self, world=None):
