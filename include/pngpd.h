@@ -125,8 +125,11 @@ int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, in
  * array inside the library, PNGPD_NOALLOC_MAX_B * 11.3 KB = 2.9 MB, which every GPU the library runs on holds
  * until the process ends; its address is looked up once per device in pngpd_model_create.  The call itself
  * allocates and frees nothing.  Same arguments, kernels and results (bit for bit) as pngpd_forward_infer;
- * B > PNGPD_NOALLOC_MAX_B returns PNGPD_ERR_SHAPE.  All calls on one GPU share the one array: two calls that
- * overlap on a GPU (different streams or threads) race; calls on one stream are ordered and safe.
+ * B > PNGPD_NOALLOC_MAX_B returns PNGPD_ERR_SHAPE.  All calls on one GPU share the one array, so two forwards
+ * that overlap on a GPU would race; calls on one stream are ordered and safe, and a call on ANOTHER stream (or from
+ * another thread) while the previous forward has not finished on the GPU is refused with PNGPD_ERR_STATE (checked
+ * with an event created in pngpd_model_create and recorded behind every forward; the check is skipped while the
+ * stream is being captured into a graph, where the caller orders the launches).
  */
 #define PNGPD_NOALLOC_MAX_B 256
 int pngpd_forward_infer_noalloc(const pngpd_model* m, const float* x_dev, int layout, int B, int P,

@@ -164,7 +164,19 @@ class _StorageType:
 
 
 def _rebuild_tensor_v2(storage, storage_offset, size, stride, requires_grad=False, backward_hooks=None, metadata=None):
-    return torch.empty(0, dtype=storage.dtype).set_(storage.untyped(), storage_offset, tuple(size), tuple(stride))
+    # Tensor.set_ grows a resizable storage to fit the view it is given, so a file could declare a tiny storage and
+    # a huge shape and have the memory allocated here, before any later check: the extent of the view is compared
+    # with the storage first.
+    size, stride = tuple(size), tuple(stride)
+    if len(size) != len(stride) or any((not isinstance(v, int)) or v < 0 for v in size + stride) \
+            or not isinstance(storage_offset, int) or storage_offset < 0:
+        raise pickle.UnpicklingError("tensor record with negative or non-integer size, stride or offset")
+    extent = 0 if 0 in size else storage_offset + sum((n - 1) * st for n, st in zip(size, stride)) + 1
+    itemsize = torch.empty(0, dtype=storage.dtype).element_size()
+    if extent * itemsize > storage.untyped().nbytes():
+        raise pickle.UnpicklingError(f"tensor record of {extent} elements does not fit its storage of "
+                                     f"{storage.untyped().nbytes()} bytes")
+    return torch.empty(0, dtype=storage.dtype).set_(storage.untyped(), storage_offset, size, stride)
 
 
 def _rebuild_tensor(storage, storage_offset, size, stride):

@@ -212,6 +212,19 @@ namespace {
 constexpr int MAX_DEVICES = 64;
 std::atomic<float*> g_scratch_addr[MAX_DEVICES];
 
+// One array per GPU serves every model and stream, so two forwards that overlap on a GPU would overwrite each other's
+// intermediates.  The library cannot order them, but it can tell: per device, a flag says that a thread is inside the
+// call, and an event recorded behind the last forward says whether the GPU is still working on it.  A call on a
+// different stream (or thread) before that event has completed is refused with PNGPD_ERR_STATE instead of racing.
+// The event is created at set-up (pngpd_model_create); the call itself only records and queries it.
+struct ScratchUse {
+    std::atomic<int> in_call{0};
+    std::atomic<hipEvent_t> done{nullptr};
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
+};
+ScratchUse g_scratch_use[MAX_DEVICES];
+
 // Device address of `scratch` on device `dev`, which must be the current device.  Looked up once per device.
 int scratch_on_current_device(int dev, float** out) {
     if (dev < 0 || dev >= MAX_DEVICES) return fail(PNGPD_ERR_INVALID, "device ordinal %d out of range", dev);
@@ -225,6 +238,19 @@ int scratch_on_current_device(int dev, float** out) {
         g_scratch_addr[dev].store(p, std::memory_order_release);
     }
     *out = p;
+    return PNGPD_OK;
+}
+
+// set-up only (allocates): the event behind which a device's scratch array is free again
+int scratch_event_on_current_device(int dev) {
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(PNGPD_ERR_INVALID, "device ordinal %d out of range", dev);
+    if (g_scratch_use[dev].done.load(std::memory_order_acquire)) return PNGPD_OK;
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return fail(PNGPD_ERR_HIP, "hipEventCreate on device %d: %s", dev, hipGetErrorString(e));
+    hipEvent_t expected = nullptr;
+    if (!g_scratch_use[dev].done.compare_exchange_strong(expected, ev, std::memory_order_acq_rel))
+        (void)hipEventDestroy(ev);            // another thread was first
     return PNGPD_OK;
 }
 }  // namespace
@@ -248,6 +274,7 @@ int pngpd_model_create(pngpd_model** out, int num_points, int k, int parts) {
     float* scratch_addr = nullptr;   // resolved here, at set-up, so that the first no-allocation forward only reads it
     int rc = scratch_on_current_device(dev, &scratch_addr);
     if (rc) return rc;
+    if ((rc = scratch_event_on_current_device(dev))) return rc;
     pngpd_model* m = new (std::nothrow) pngpd_model();
     if (!m) return fail(PNGPD_ERR_INVALID, "out of host memory");
     m->device = dev;
@@ -387,9 +414,33 @@ int pngpd_forward_infer_noalloc(const pngpd_model* m, const float* x_dev, int la
     float* ws = nullptr;
     int rc = scratch_on_current_device(dev, &ws);
     if (rc) return rc;
+    ScratchUse& use = g_scratch_use[dev];
+    hipEvent_t done = use.done.load(std::memory_order_acquire);
+    if (!done) return fail(PNGPD_ERR_STATE, "pngpd_forward_infer_noalloc: no model was created on device %d", dev);
+    if (use.in_call.exchange(1, std::memory_order_acquire) != 0)
+        return fail(PNGPD_ERR_STATE, "pngpd_forward_infer_noalloc: another thread is inside the call on device %d "
+                    "(all calls on a GPU share one scratch array)", dev);
+    struct Leave {
+        std::atomic<int>& f;
+        ~Leave() { f.store(0, std::memory_order_release); }
+    } leave{use.in_call};
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &capturing);       // an event recorded under capture cannot be queried: skip the check
+    if (capturing == hipStreamCaptureStatusNone && use.has_last && use.last_stream != s &&
+        hipEventQuery(done) == hipErrorNotReady)
+        return fail(PNGPD_ERR_STATE, "pngpd_forward_infer_noalloc: the scratch array of device %d is still in use by a "
+                    "forward on another stream (synchronise the two streams, or use pngpd_forward_infer with a "
+                    "workspace per stream)", dev);
     // every float of the workspace that a forward reads is written earlier in the same forward: nothing to clear
-    return forward_impl(m, x_dev, layout, B, P, precision, logp_dev, trans_dev, feat_dev, ws,
-                        SCRATCH_FLOATS * sizeof(float), stream, nullptr);
+    rc = forward_impl(m, x_dev, layout, B, P, precision, logp_dev, trans_dev, feat_dev, ws,
+                      SCRATCH_FLOATS * sizeof(float), stream, nullptr);
+    if (rc == PNGPD_OK && capturing == hipStreamCaptureStatusNone) {
+        HIP_TRY(hipEventRecord(done, s));
+        use.last_stream = s;
+        use.has_last = true;
+    }
+    return rc;
 }
 
 int pngpd_forward_infer_timed(const pngpd_model* m, const float* x_dev, int layout, int B, int P,

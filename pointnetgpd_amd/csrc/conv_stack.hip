@@ -336,6 +336,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
     for (int i = tid; i < C3; i += WS_THREADS) s_b3[i] = a.b3[i];
     if (tid < 2 * 4 * 16)                          // k slots 24..31 of both tables stay zero for the whole kernel
         *(u32x4*)(s_w1f + (tid >> 6) * W1F_BYTES + ((((tid >> 4) & 3) * 4 + 3) * 16 + (tid & 15)) * 16) = u32x4{0u, 0u, 0u, 0u};
+    lds_dma_wait();
     __syncthreads();
 
     const int ntiles = (a.P + 15) >> 4;
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_stack_f32_kernel(ConvStackArg
     if (tid < C1) s_w1[tid] = fold_w1(a, b, tid);
     if (tid < B2P_FLOATS) s_b2[tid] = a.b2p[tid];
     for (int c = tid; c < WAVES * C3; c += THREADS) s_red[c] = -INFINITY;
+    lds_dma_wait();
     __syncthreads();
 
     float* s_red_wave = s_red + wave * C3;
@@ -594,6 +596,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_stack_f32_kernel(ConvStackArg
                             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                                 X[mt][t][4 * (q & 3) + e], bw[e], acc[mt], 0, 0, 0);
                 }
+                lds_dma_wait();         // the chunk issued at the top of this half: long landed behind the MFMAs
                 __syncthreads();
             }
             float m = -INFINITY;

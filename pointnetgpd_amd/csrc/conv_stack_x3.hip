@@ -267,6 +267,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
     for (int i = tid; i < C3; i += X3_THREADS) s_b3[i] = a.b3[i];
     if (tid < 2 * 4 * 16)                          // k slots 24..31 of both layer-1 tables stay zero for the whole kernel
         *(u32x4*)(s_w1f + (tid >> 6) * W1F_BYTES + ((((tid >> 4) & 3) * 4 + 3) * 16 + (tid & 15)) * 16) = u32x4{0u, 0u, 0u, 0u};
+    lds_dma_wait();
     __syncthreads();
 
     const int ntiles = (a.P + 15) >> 4;

@@ -315,6 +315,7 @@ __global__ __launch_bounds__(256) void fc_bf16x3_kernel(const float* __restrict_
     stage_b(0, smem);
     load_a(0, v0, v1);
     store_a(v0, v1, smem);
+    lds_dma_wait();
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
         char* cur = smem + (kb & 1) * STAGE;
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(256) void fc_bf16x3_kernel(const float* __restrict_
             }
         }
         if (more) store_a(v0, v1, nxt);
+        lds_dma_wait();             // the weight pieces issued at the top of this step
         __syncthreads();
     }
 #pragma unroll

@@ -14,6 +14,13 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Waits until this wave's LDS-DMA transfers (global_load ... lds) have landed.  An LDS-DMA is a vector-memory operation:
+// the workgroup release in front of a barrier orders LDS operations only, and the compiler counts a wave's
+// outstanding transfers only for that wave's own reads.  A barrier that publishes DMA'd bytes to OTHER waves therefore
+// needs every wave to drain its transfers first.  (s_waitcnt immediate on gfx9: vmcnt = bits 3:0 and 15:14, expcnt =
+// bits 6:4, lgkmcnt = bits 11:8; 0x0F70 = vmcnt(0) with the other two counters left alone.)
+__device__ __forceinline__ void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 constexpr int C1 = 64;     // conv1 output channels
 constexpr int C2 = 128;    // conv2 output channels
 constexpr int C3 = 1024;   // conv3 output channels

@@ -496,6 +496,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void conv3_pool_train_kernel(const f
         s_red[c] = -INFINITY;
         s_arg[c] = 0;
     }
+    lds_dma_wait();
     __syncthreads();
 
     float* s_red_wave = s_red + wave * nch;
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void conv3_pool_train_kernel(const f
                             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(X[mt][t][4 * (q & 3) + e], bw[e], acc[mt], 0,
                                                                           0, 0);
                 }
+                lds_dma_wait();         // the chunk issued at the top of this half landed long ago, behind the MFMAs
                 __syncthreads();
             }
             // accumulator register i of lane half hh is point (i&3) + 8(i>>2) + 4hh of the tile, channel 32nt + r:
@@ -642,6 +644,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void conv3_pool_train_x6_kernel(cons
         s_red[c] = -INFINITY;
         s_arg[c] = 0;
     }
+    lds_dma_wait();
     __syncthreads();
 
     float* s_red_wave = s_red + wave * nch;
@@ -708,6 +711,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void conv3_pool_train_x6_kernel(cons
 #pragma unroll
                     for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[mt][ks], bh, acc[mt], 0, 0, 0);
                 }
+                lds_dma_wait();         // the chunk issued at the top of this half landed long ago, behind the MFMAs
                 __syncthreads();
             }
             // accumulator register i of lane half hh is point (i&3) + 8(i>>2) + 4hh of the tile, channel 32nt + r:
@@ -1035,8 +1039,10 @@ hipError_t t_conv3_fwd(float* h2, const float* W3, const float* b3, const float*
     int cs = 1;
     while (cs < 8 && B * cs < 2 * n_cu) cs *= 2;
     const int ntb = 32 / cs;
-    // PNGPD_TRAIN_CONV3=f32 keeps the product on the float32 matrix instruction (the split-bfloat16 form is the default)
-    static const bool use_f32 = [] { const char* v = getenv("PNGPD_TRAIN_CONV3"); return v && v[0] == 'f'; }();
+    // PNGPD_TRAIN_CONV3=f32 keeps the product on the float32 matrix instruction (the split-bfloat16 form is the default);
+    // read at every call, like PNGPD_TRAIN_GRAM above
+    const char* conv3_env = getenv("PNGPD_TRAIN_CONV3");
+    const bool use_f32 = conv3_env && conv3_env[0] == 'f';
     if (use_f32 || w.w3s == nullptr) {
         const size_t lds = 2 * TC_CHUNK_BYTES + (size_t)TC_WAVES * 32 * ntb * 8;
         e = hipFuncSetAttribute((const void*)conv3_pool_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

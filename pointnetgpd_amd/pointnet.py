@@ -84,7 +84,8 @@ class _HipBacked(nn.Module):
 
     def __getstate__(self):
         state = dict(self.__dict__)
-        state.pop("_hip", None)   # device handles never travel through pickle / deepcopy
+        state.pop("_hip", None)   # device handles never travel through pickle / deepcopy,
+        state.pop("_sig_cache", None)   # nor does the process-local list of tensors and device addresses
         return state
 
     def _tensors(self):
@@ -96,12 +97,14 @@ class _HipBacked(nn.Module):
 
     # ---- when do the packed device weights have to be rebuilt? -------------------------------------------------
     # Values change in place (optimizer steps, load_state_dict, manual edits under no_grad): every such write bumps
-    # the tensor's autograd version counter, and the counters of the module's tensors are polled on every forward -
-    # one attribute read each, from a cached list.  The tensors THEMSELVES change (another storage or another
-    # Parameter object) through .to() / .cuda() / .float() (nn.Module._apply), load_state_dict(assign=True) or by
-    # assigning a new sub-module or Parameter to a module of this package; those paths bump _STRUCTURE below, which
-    # drops the cached list.  What nothing here can see is a Parameter assigned straight onto a plain torch layer
-    # (`model.fc3.weight = nn.Parameter(...)`): call invalidate_packed_weights() after that.
+    # the tensor's autograd version counter.  A tensor's STORAGE changes without a version bump through
+    # `param.data = t` (torch.nn.utils.vector_to_parameters, EMA / SWA weight swaps, flattening parameters into one
+    # buffer).  Both are polled on every forward - one attribute read and one data_ptr() each, from a cached list of
+    # the module's tensors.  The tensor OBJECTS change through .to() / .cuda() / .float() (nn.Module._apply),
+    # load_state_dict(assign=True) or by assigning a new sub-module or Parameter to a module of this package; those
+    # paths bump _STRUCTURE below, which drops the cached list.  What nothing here can see is a Parameter assigned
+    # straight onto a plain torch layer (`model.fc3.weight = nn.Parameter(...)`): call invalidate_packed_weights()
+    # after that.
     def _apply(self, fn, *args, **kwargs):
         _STRUCTURE[0] += 1
         return super()._apply(fn, *args, **kwargs)
@@ -118,12 +121,13 @@ class _HipBacked(nn.Module):
     def _weights_signature(self):
         cache = self.__dict__.get("_sig_cache")
         if cache is None or cache[0] != _STRUCTURE[0]:
-            tensors = list(self._tensors())
-            cache = self.__dict__["_sig_cache"] = (_STRUCTURE[0], tensors, tuple(t.data_ptr() for t in tensors))
+            cache = self.__dict__["_sig_cache"] = (_STRUCTURE[0], list(self._tensors()))
         versions = 0
-        for t in cache[1]:
+        ptrs = 0
+        for i, t in enumerate(cache[1]):
             versions += t._version
-        return (_GENERATION[0], versions, cache[2])
+            ptrs ^= t.data_ptr() * (2 * i + 1)      # order-sensitive digest of the storages' addresses
+        return (_GENERATION[0], versions, ptrs)
 
     def _handle(self, device: torch.device) -> _Handle:
         h = self.__dict__.get("_hip")

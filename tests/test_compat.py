@@ -177,6 +177,47 @@ def test_legacy_reader_resolves_nothing_outside_its_table(tmp_path):
         compat.load_checkpoint(big, device="cpu")
 
 
+def test_legacy_reader_checks_a_tensor_against_its_storage_before_building_it(tmp_path):
+    """A tensor record whose shape reaches beyond its storage is refused before Tensor.set_ could grow the storage to
+    fit it: a 12-byte storage with a declared shape of 2**28 floats must not allocate a gigabyte."""
+    import pickle
+    import warnings
+    path = str(tmp_path / "small.model")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.save({"weights": torch.zeros(3)}, path, _use_new_zipfile_serialization=False)
+    blob = open(path, "rb").read()
+    at = blob.index(b"K\x03\x85", blob.index(b"_rebuild_tensor_v2"))       # the size tuple (3,)
+    forged = blob[:at] + b"J" + (2 ** 28).to_bytes(4, "little") + blob[at + 2:]
+    bad = str(tmp_path / "forged.model")
+    open(bad, "wb").write(forged)
+    with pytest.raises(pickle.UnpicklingError, match="does not fit its storage"):
+        compat.load_checkpoint(bad, device="cpu")
+    store = compat._LegacyStorage(torch.UntypedStorage(16), torch.float32)
+    for args in ((0, (1000, 1000), (1000, 1)), (3, (2,), (1,)), (0, (2, 3), (4, 1)), (-1, (2,), (1,)), (0, (2,), (-1,))):
+        with pytest.raises(pickle.UnpicklingError):
+            compat._rebuild_tensor_v2(store, *args)
+    assert store.untyped().nbytes() == 16
+    assert compat._rebuild_tensor_v2(store, 1, (3,), (1,)).shape == (3,)
+    assert compat._rebuild_tensor_v2(store, 0, (0, 99), (99, 1)).numel() == 0
+
+
+def test_saved_modules_carry_no_process_local_state(tmp_path):
+    """The cached tensor list that decides when device weights are repacked is process-local: it must not travel
+    into whole-module files (which the reference's torch.load is meant to read) nor into deep copies."""
+    import copy
+    m = pn.PointNetCls(16, 3, 2)
+    m._weights_signature()
+    m.feat._weights_signature()
+    assert "_sig_cache" in m.__dict__
+    assert "_sig_cache" not in copy.deepcopy(m).__dict__
+    for old in (True, False):
+        path = str(tmp_path / f"after_forward_{old}.model")
+        compat.save_checkpoint(m, path, old_container=old)
+        assert b"_sig_cache" not in open(path, "rb").read()
+        assert b"_hip" not in open(path, "rb").read()
+
+
 REFERENCE = "/root/reference"
 
 

@@ -161,6 +161,27 @@ def test_weights_repacked_after_in_place_update():
     assert not torch.equal(a, b)
 
 
+def test_weights_repacked_after_storage_swap():
+    """`param.data = t` (vector_to_parameters, EMA / SWA swaps) gives a parameter another storage without bumping its
+    version counter; the next eval forward must score with the new values."""
+    m = hip_model(750, 2, 35, 1.0, "fp32")
+    x = torch.from_numpy(synth.candidate_points(35, 2, 750, "normal")).cuda()
+    a, _ = m(x)
+    version = m.fc3.weight._version
+    m.fc3.weight.data = (m.fc3.weight.data * 0.5).clone()
+    assert m.fc3.weight._version == version          # nothing but the address tells
+    b, _ = m(x)
+    assert not torch.equal(a, b)
+    flat = torch.nn.utils.parameters_to_vector(m.parameters()).detach().clone()
+    torch.nn.utils.vector_to_parameters(flat * 1.01, m.parameters())
+    c, _ = m(x)
+    assert not torch.equal(b, c)
+    oracle = po.build_cls(750, 2, {k: v.detach().cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        ref, _ = oracle(x.cpu())
+    assert (c.cpu() - ref).abs().max().item() <= FP32_ATOL
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_full_size_properties(precision):
     """B=4096, P=750 in every arithmetic mode: results do not depend on batch position, batch size or

@@ -76,3 +76,30 @@ def test_no_alloc_forward_refuses_a_batch_beyond_its_maximum():
     assert rc == 2 and "at most 256" in h.lib.pngpd_last_error().decode()
     rc = h.lib.pngpd_forward_infer_noalloc(h.ptr, vp(x), _lib.LAYOUT_C3P, B - 1, P + 1, _lib.FP32, vp(out), None, None, st)
     assert rc == 2 and "num_points" in h.lib.pngpd_last_error().decode()
+
+
+def test_no_alloc_forward_refuses_to_overlap_on_two_streams():
+    """All forwards on a GPU share the one scratch array.  A call on another stream while the previous forward is
+    still running on the GPU would corrupt it: the library refuses the call (PNGPD_ERR_STATE) instead; once the
+    first stream has drained, the same call goes through and gives the same rows."""
+    P, k, B = 750, 2, _lib.NOALLOC_MAX_B
+    m = PointNetCls(P, 3, k)
+    m.load_state_dict(synth.torch_state_dict(5, k, 0.02))
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth.candidate_points(5, B, P)).cuda()
+    ref = m(x)[0]
+    h = m._handle(x.device)
+    prec = _lib.PRECISIONS[str(m.precision)]
+    out1, out2 = torch.empty((B, k), device="cuda"), torch.empty((B, k), device="cuda")
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    st1, st2 = ctypes.c_void_p(s1.cuda_stream), ctypes.c_void_p(s2.cuda_stream)
+    call = h.lib.pngpd_forward_infer_noalloc
+    for _ in range(300):        # a queue the GPU needs tens of milliseconds for; enqueueing it takes the host far less
+        assert call(h.ptr, vp(x), _lib.LAYOUT_C3P, B, P, prec, vp(out1), None, None, st1) == 0
+    rc = call(h.ptr, vp(x), _lib.LAYOUT_C3P, B, P, prec, vp(out2), None, None, st2)
+    assert rc == 4 and "another stream" in h.lib.pngpd_last_error().decode()
+    s1.synchronize()
+    assert call(h.ptr, vp(x), _lib.LAYOUT_C3P, B, P, prec, vp(out2), None, None, st2) == 0
+    s2.synchronize()
+    assert torch.equal(out1, ref) and torch.equal(out2, ref)
