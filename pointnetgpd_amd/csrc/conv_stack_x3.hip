@@ -3,9 +3,9 @@
 //     pooled[b, :] = act( max_p  W3 * relu(W2 * relu(W1 * T_b^T x[b,p] + b1) + b2) ) + b3
 //
 // (STN3d.forward, model/pointnet.py:30-34, and PointNetfeat.forward, model/pointnet.py:138-147, with eval-mode
-// BatchNorm folded into W/b), same structure as conv_stack_bf16_kernel (conv_stack.hip): layer 2 transposed so that its
-// accumulators are layer 3's A operand, layer-3 weights stationary in registers, A fragments through a double buffer
-// in LDS, per-lane running maxima.  What differs is the arithmetic.  Every operand of layers 2 and 3 is TWO bf16
+// BatchNorm folded into W/b), with the data flow of conv_stack_bf16_kernel (conv_stack.hip): layer 2 transposed so that
+// its accumulators are layer 3's A operand, layer-3 weights stationary in registers, A fragments through a double
+// buffer in LDS, per-lane running maxima.  What differs is the arithmetic (below) and the instruction stream (woven).  Every operand of layers 2 and 3 is TWO bf16
 // numbers, v = hi + lo + r with hi = bf16(v), lo = bf16(v - hi) (both round-to-nearest, so |r| <= 2^-18 |v|), and a
 // product is three MFMAs accumulating in float32:
 //
@@ -28,10 +28,6 @@
 
 namespace pngpd {
 
-#ifndef X3_PRIO_PRODUCE
-#define X3_PRIO_PRODUCE 0
-#define X3_PRIO_CONSUME 3
-#endif
 constexpr int X3_WAVES = 8;
 constexpr int X3_THREADS = X3_WAVES * 64;
 constexpr int X3_PLANE_BYTES = 4096;                       // [ks4][lane64][16 B]
@@ -80,91 +76,6 @@ __device__ __forceinline__ float load_tile_point(const ConvStackArgs& a, int b, 
     return q < 3 ? a.x[at] : 0.f;
 }
 
-// conv2 fragments of one pair of row tiles (2ks, 2ks+1): [row tile][k-step]
-struct X3W2 {
-    bf16x8 w[2][2];
-};
-
-__device__ __forceinline__ void load_w2_pair(X3W2& f, int ks, const char* img, int lane) {
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) f.w[tt][s] = *(const bf16x8*)(img + (((2 * ks + tt) * 2 + s) * 64 + lane) * 16);
-}
-
-// The same fragments from memory, as buffer loads: scalar resource + one 32-bit lane offset + a constant, so that the
-// sixteen loads of a produce step share one address register (as flat loads the compiler keeps sixteen 64-bit
-// addresses alive across the whole kernel).
-__device__ __forceinline__ void load_w2_pair_global(X3W2& f, int ks, __amdgpu_buffer_rsrc_t img, unsigned int lane16) {
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-            f.w[tt][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(img, lane16, ((2 * ks + tt) * 2 + s) * 1024, 0));
-}
-#ifdef X3_ABL_W2LO_LDS   // timing only: the lo image read from where the hi image lies
-#define load_w2_pair_global(f, ks, img, lane16) load_w2_pair(f, ks, s_w2h, lane)
-#endif
-
-// Layers 1-2 of one tile of 16 points; the two planes of its layer-3 A fragments go to dst, dst + X3_PLANE_BYTES.
-__device__ __forceinline__ void produce_tile_x3(float px, const char* s_w1f, unsigned int ones, const char* s_w2h,
-                                                __amdgpu_buffer_rsrc_t g_w2l, const float* s_b2, char* dst, int lane) {
-    const int q = lane >> 4;
-    bf16x8 w1f[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) w1f[t] = *(const bf16x8*)(s_w1f + (t * 64 + lane) * 16);
-    X3W2 lo_a, lo_b;
-    const unsigned int lane16 = (unsigned int)lane * 16u;
-    load_w2_pair_global(lo_a, 0, g_w2l, lane16);
-    // layer 1: the lane's eight k slots are made from one coordinate of its point (conv_stack.hip)
-    bf16x8 xb;
-    {
-        const unsigned int x = f2u(px);
-        const float r1 = px - u2f(x & 0xffff0000u);
-        const unsigned int m = f2u(r1);
-        const unsigned int l = f2u(r1 - u2f(m & 0xffff0000u));
-        u32x4 v;
-        v[0] = __builtin_amdgcn_perm(x, x, 0x03020302u);      // xh, xh
-        v[1] = __builtin_amdgcn_perm(x, m, 0x07060302u);      // xm, xh
-        v[2] = __builtin_amdgcn_perm(l, m, 0x07060302u);      // xm, xl
-        v[3] = ones;
-        xb = __builtin_bit_cast(bf16x8, v);
-    }
-    const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
-    bf16x8 hbh[2], hbl[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const f32x4v h1a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[2 * s], xb, zero, 0, 0, 0);
-        const f32x4v h1b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[2 * s + 1], xb, zero, 0, 0, 0);
-        relu_split(h1a, h1b, hbh[s], hbl[s]);
-    }
-    // layer 2, transposed: per pair of row tiles six MFMAs per tile, small terms first
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        X3W2& lo_cur = (ks & 1) ? lo_b : lo_a;
-        X3W2& lo_nxt = (ks & 1) ? lo_a : lo_b;
-        if (ks + 1 < 4) load_w2_pair_global(lo_nxt, ks + 1, g_w2l, lane16);
-        X3W2 hi;
-        load_w2_pair(hi, ks, s_w2h, lane);
-        f32x4v acc[2];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) acc[tt] = *(const f32x4v*)(s_b2 + 16 * (2 * ks + tt) + 4 * q);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo_cur.w[tt][s], hbh[s], acc[tt], 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi.w[tt][s], hbl[s], acc[tt], 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi.w[tt][s], hbh[s], acc[tt], 0, 0, 0);
-        }
-        bf16x8 H, L;
-        relu_split(acc[0], acc[1], H, L);
-        *(bf16x8*)(dst + (ks * 64 + lane) * 16) = H;
-        *(bf16x8*)(dst + X3_PLANE_BYTES + (ks * 64 + lane) * 16) = L;
-    }
-}
-
 struct X3AFrag {
     bf16x8 h[4], l[4];
 };
@@ -178,57 +89,132 @@ __device__ __forceinline__ void load_afrags_x3(X3AFrag& f, const char* tile, int
 
 // One channel tile against one point tile: a chain of 12 MFMAs accumulating in place (a dependent chain of this
 // instruction issues at the pipe's full rate, conv_stack.hip), the two small piece products of every k-step first.
+// The lo plane of the activations goes first: its registers are free after a third of the chain, the hi plane's
+// only one by one at the end, which is the order in which the woven kernel refills them for the next tile.
 __device__ __forceinline__ f32x4v mfma_chain12(const X3AFrag& f, const bf16x8 (&wh)[4], const bf16x8 (&wl)[4]) {
     f32x4v z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.h[k], wl[k], z, 0, 0, 0);
-#pragma unroll
     for (int k = 0; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.l[k], wh[k], z, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.h[k], wl[k], z, 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.h[k], wh[k], z, 0, 0, 0);
     return z;
 }
 
-// One tile of 16 points against the wave's NT channel tiles; the max-reduction of a chain is issued behind the
-// following chain, `carry` hands the last chain of a tile over to the next call.
-template <int NT>
-__device__ __forceinline__ void consume_tile_x3(const X3AFrag& f, const bf16x8 (&bwh)[NT][4], const bf16x8 (&bwl)[NT][4],
-                                                f32x4v& carry, float (&rm)[NT]) {
-    f32x4v accA = carry, accB;
+// ------------------------------------------------------------------------------------------------------------------
+// The produce work is WOVEN into the consume stream.
+//
+// A first form of this kernel followed conv_stack_bf16_kernel: once per batch a wave left the consume loop for a
+// produce step of ~250 vector and 52 matrix instructions.  Every wave here runs ONE instruction stream instead, in
+// which the produce instructions of its tile sit in the issue slots that its own MFMAs leave free: a batch is 8
+// tiles, tile step t carries row tile t of layer 2 (a chain of six MFMAs behind the step's first chain, the split of
+// its result and the LDS traffic spread at one instruction per MFMA gap), and layer 1 of the tile after next closes
+// the batch.  Nothing branches inside a batch: batches are always 8 tiles (rows beyond P repeat the last point, which
+// cannot change a maximum) and a workgroup's last batch produces a tile that nobody reads.
+// A wave consumes the tiles of a batch starting with its own (the one it produced): those fragments are fetched
+// before the barrier that publishes the batch, so no LDS latency is exposed behind it.  Fragment registers are
+// refilled in place: the lo plane of the next tile as soon as the last chain of a tile has used the current one (a
+// third into the chain), the hi plane fragment by fragment behind the chain's last four MFMAs.
+// Measured against the first form at B = 4096, P = 750 (one box, alternating): 1.42 -> 1.40 ms per launch; counters:
+// matrix pipe 84 % busy at the 2.15 GHz the chip holds under this load; the same stream without the produce
+// instructions runs at 96 %.
+// ------------------------------------------------------------------------------------------------------------------
+#define X3_SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define X3_SGB_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
+#define X3_SGB_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define X3_SGB_DSW(n) __builtin_amdgcn_sched_group_barrier(0x200, n, 0)
+#define X3_SGB_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
+#define X3_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// conv2 fragments of one row tile: hi image from LDS, lo image from memory, [k-step]
+struct X3W2Row {
+    bf16x8 hi[2], lo[2];
+    f32x4v bias;
+};
+
+__device__ __forceinline__ void load_w2_row_lds(X3W2Row& f, int T, const char* s_w2h, const float* s_b2, int lane) {
 #pragma unroll
-    for (int n = 0; n < NT; n += 2) {
-        accB = mfma_chain12(f, bwh[n], bwl[n]);
-        __builtin_amdgcn_sched_barrier(0);
-        const int pn = (n + NT - 1) & (NT - 1);
-        rm[pn] = max3(rm[pn], max3(accA[0], accA[1], accA[2]), accA[3]);
-        __builtin_amdgcn_sched_barrier(0);
-        accA = mfma_chain12(f, bwh[n + 1], bwl[n + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        rm[n] = max3(rm[n], max3(accB[0], accB[1], accB[2]), accB[3]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    carry = accA;
+    for (int s = 0; s < 2; ++s) f.hi[s] = *(const bf16x8*)(s_w2h + ((T * 2 + s) * 64 + lane) * 16);
+    f.bias = *(const f32x4v*)(s_b2 + 16 * T + 4 * (lane >> 4));
 }
 
-// Diagnostic build only (-DPNGPD_STAMPS, tools/diag): shader-clock stamps of workgroup 0 go to a buffer of their own;
-// no output value depends on them.  The product build compiles none of it.
-#ifdef PNGPD_STAMPS
-constexpr int X3_STAMP_FIRST = 7, X3_STAMP_BATCHES = 6, X3_STAMP_EVENTS = 5;
-__device__ unsigned long long g_stamps_x3[X3_WAVES][X3_STAMP_BATCHES * X3_STAMP_EVENTS];
-__device__ unsigned long long g_stamp_clock_x3[4];
-#define X3_STAMP(g, ev)                                                                                   \
-    do {                                                                                                  \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (g) >= X3_STAMP_FIRST &&                    \
-            (g) < X3_STAMP_FIRST + X3_STAMP_BATCHES)                                                      \
-            g_stamps_x3[wave][((g)-X3_STAMP_FIRST) * X3_STAMP_EVENTS + (ev)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define X3_STAMP(g, ev)
-#endif
+__device__ __forceinline__ void load_w2_row_mem(X3W2Row& f, int T, __amdgpu_buffer_rsrc_t g_w2l, unsigned int lane16) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        f.lo[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(g_w2l, lane16, (T * 2 + s) * 1024, 0));
+}
 
-// NT = channel tiles of 16 per wave.  4 is the throughput shape: a workgroup covers 512 channels, grid.y = 2.  A batch
-// too small to give every CU a workgroup runs NT = 2 with grid.y = 4.  The arithmetic of a channel does not depend on
-// the cut, so a candidate's result does not depend on the batch it is scored in.
+// one row tile of layer 2 for one point tile: bias, then the small piece products, then the large ones
+__device__ __forceinline__ f32x4v l2_row_chain(const X3W2Row& w, const bf16x8 (&hbh)[2], const bf16x8 (&hbl)[2]) {
+    f32x4v acc = w.bias;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.lo[s], hbh[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi[s], hbl[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi[s], hbh[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// layer 1 of one tile: lane's coordinate -> the hi / lo B fragments of layer 2
+__device__ __forceinline__ void layer1_x3(float px, const char* s_w1f, unsigned int ones, int lane, bf16x8 (&hbh)[2],
+                                          bf16x8 (&hbl)[2]) {
+    bf16x8 w1f[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w1f[t] = *(const bf16x8*)(s_w1f + (t * 64 + lane) * 16);
+    const unsigned int x = f2u(px);
+    const float r1 = px - u2f(x & 0xffff0000u);
+    const unsigned int m = f2u(r1);
+    const unsigned int l = f2u(r1 - u2f(m & 0xffff0000u));
+    u32x4 v;
+    v[0] = __builtin_amdgcn_perm(x, x, 0x03020302u);      // xh, xh
+    v[1] = __builtin_amdgcn_perm(x, m, 0x07060302u);      // xm, xh
+    v[2] = __builtin_amdgcn_perm(l, m, 0x07060302u);      // xm, xl
+    v[3] = ones;
+    const bf16x8 xb = __builtin_bit_cast(bf16x8, v);
+    const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f32x4v h1a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[2 * s], xb, zero, 0, 0, 0);
+        const f32x4v h1b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[2 * s + 1], xb, zero, 0, 0, 0);
+        relu_split(h1a, h1b, hbh[s], hbl[s]);
+    }
+}
+
+// Layers 1-2 of one tile of 16 points outright (the prologue's first batch); the two planes of its layer-3 A fragments
+// go to dst, dst + X3_PLANE_BYTES.  Same arithmetic, instruction for instruction, as the woven steps of the kernel.
+__device__ __forceinline__ void produce_tile_x3(float px, const char* s_w1f, unsigned int ones, const char* s_w2h,
+                                                __amdgpu_buffer_rsrc_t g_w2l, const float* s_b2, char* dst, int lane) {
+    bf16x8 hbh[2], hbl[2];
+    layer1_x3(px, s_w1f, ones, lane, hbh, hbl);
+    const unsigned int lane16 = (unsigned int)lane * 16u;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        unsigned int h[4], l[4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            X3W2Row w;
+            load_w2_row_lds(w, 2 * ks + tt, s_w2h, s_b2, lane);
+            load_w2_row_mem(w, 2 * ks + tt, g_w2l, lane16);
+            const f32x4v acc = l2_row_chain(w, hbh, hbl);
+            relu_split2(acc[0], acc[1], h[2 * tt], l[2 * tt]);
+            relu_split2(acc[2], acc[3], h[2 * tt + 1], l[2 * tt + 1]);
+        }
+        *(u32x4*)(dst + (ks * 64 + lane) * 16) = u32x4{h[0], h[1], h[2], h[3]};
+        *(u32x4*)(dst + X3_PLANE_BYTES + (ks * 64 + lane) * 16) = u32x4{l[0], l[1], l[2], l[3]};
+    }
+}
+
+// Running maximum over one accumulator, as two v_max3.  The empty asm makes the result opaque: in the unrolled batch
+// the compiler otherwise re-associates the maxima of all tiles into one tree at the end of the batch and keeps
+// every accumulator alive (in scratch memory) until then.
+__device__ __forceinline__ float pinned_max(float m, const f32x4v& v) {
+    m = max3(m, max3(v[0], v[1], v[2]), v[3]);
+    asm volatile("" : "+v"(m));
+    return m;
+}
+
 template <int NT>
 __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs a) {
     static_assert(NT == 4 || NT == 2, "channel tiles per wave");
@@ -236,6 +222,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: scalar branches and addresses
     const int c = lane & 15, q = lane >> 4;
+    const unsigned int lane16 = (unsigned int)lane * 16u;
 
     char* s_a = smem;
     char* s_w2 = smem + X3_OFF_W2;
@@ -243,11 +230,10 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
     float4* s_w1base = (float4*)(smem + X3_OFF_W1B);
     char* s_w1f = smem + X3_OFF_W1;
     float* s_b3 = (float*)(smem + X3_OFF_B3);
-    // conv2's lo image as a raw buffer (gfx950: 32-bit elements, no swizzle), W2P_BF16_BYTES long
     const __amdgpu_buffer_rsrc_t g_w2l = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2lo, 0, (int)W2P_BF16_BYTES, 0x00020000);
     const unsigned int ones = q == 0 ? 0x3f803f80u : q == 1 ? 0x00003f80u : 0u;
 
-    const int ct0 = ((int)blockIdx.y * X3_WAVES + wave) * NT;      // first channel tile of this wave
+    const int ct0 = ((int)blockIdx.y * X3_WAVES + wave) * NT;
     bf16x8 bwh[NT][4], bwl[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -265,48 +251,52 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
     if (tid < C2) s_b2[tid] = a.b2p[tid];
     if (tid < C1) s_w1base[tid] = a.w1tab[tid];
     for (int i = tid; i < C3; i += X3_THREADS) s_b3[i] = a.b3[i];
-    if (tid < 2 * 4 * 16)                          // k slots 24..31 of both layer-1 tables stay zero for the whole kernel
+    if (tid < 2 * 4 * 16)
         *(u32x4*)(s_w1f + (tid >> 6) * W1F_BYTES + ((((tid >> 4) & 3) * 4 + 3) * 16 + (tid & 15)) * 16) = u32x4{0u, 0u, 0u, 0u};
     lds_dma_wait();
     __syncthreads();
 
     const int ntiles = (a.P + 15) >> 4;
-    const int nbatch = (ntiles + X3_BATCH_TILES - 1) / X3_BATCH_TILES;
+    const int nbatch = (ntiles + X3_BATCH_TILES - 1) / X3_BATCH_TILES;      // every batch runs all 8 tiles
     const int stride = gridDim.x;
     const int ncand = (a.B - (int)blockIdx.x + stride - 1) / stride;
 
-    // Produce cursor: the (candidate, batch) whose tile `wave` this wave produces next; the point is loaded one step
-    // ahead.  The layer-1 table of a candidate is written by wave 0 when its cursor reaches that candidate, into the
-    // table the previous candidate does not use: the first produce step that reads it lies behind the barrier that
-    // ends the batch, and the table it replaces was last read a batch earlier.
-    int pb = blockIdx.x, pbt = 0, ptab = 0;
-    bool ptile = wave < ntiles;
+    // Layer-1 cursor: the (candidate, batch) whose tile `wave` gets its layer 1 NEXT, always two batches ahead of the
+    // batch being consumed; px is this lane's coordinate of that tile's point.  Wave 0 writes a candidate's layer-1
+    // table when the cursor reaches the candidate, into the slot the candidate before it does not use; a barrier lies
+    // between that and the first read, and the slot's previous owner was last read two barriers earlier.
+    int lb = blockIdx.x, lbt = 0, ltab = 0;
     float px = 0.f;
-    if (wave == 0) fold_w1_frags(a, pb, s_w1base, s_w1f, lane);
-    if (ptile) px = load_tile_point(a, pb, wave, c, q);
-    __syncthreads();
-    auto produce_step = [&](char* batch_base) {
-        if (ptile) produce_tile_x3(px, s_w1f + ptab * W1F_BYTES, ones, s_w2, g_w2l, s_b2, batch_base + wave * X3_TILE_BYTES, lane);
-        if (++pbt == nbatch) {
-            pbt = 0;
-            pb += stride;
-            ptab ^= 1;
-            if (wave == 0 && pb < a.B) fold_w1_frags(a, pb, s_w1base, s_w1f + ptab * W1F_BYTES, lane);
-        }
-        const int tile = pbt * X3_BATCH_TILES + wave;
-        ptile = pb < a.B && tile < ntiles;
-        if (ptile) px = load_tile_point(a, pb, tile, c, q);
+    auto fetch_point = [&]() {
+        if (lb < a.B) px = load_tile_point(a, lb, lbt * X3_BATCH_TILES + wave, c, q);
     };
-    produce_step(s_a);
+    auto advance = [&]() {
+        if (++lbt == nbatch) {
+            lbt = 0;
+            lb += stride;
+            ltab ^= 1;
+            if (wave == 0 && lb < a.B) fold_w1_frags(a, lb, s_w1base, s_w1f + ltab * W1F_BYTES, lane);
+        }
+        fetch_point();
+    };
+    bf16x8 hbh[2], hbl[2];
+    // prologue: batch 0 is produced outright, layer 1 of batch 1 is left in hbh / hbl, px belongs to batch 2
+    if (wave == 0) fold_w1_frags(a, lb, s_w1base, s_w1f, lane);
+    fetch_point();
+    __syncthreads();
+    produce_tile_x3(px, s_w1f + ltab * W1F_BYTES, ones, s_w2, g_w2l, s_b2, s_a + wave * X3_TILE_BYTES, lane);
+    advance();
+    __syncthreads();
+    layer1_x3(px, s_w1f + ltab * W1F_BYTES, ones, lane, hbh, hbl);
+    advance();
     __syncthreads();
 
-#ifdef PNGPD_STAMPS
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-        g_stamp_clock_x3[0] = __builtin_amdgcn_s_memtime();
-        g_stamp_clock_x3[1] = __builtin_amdgcn_s_memrealtime();
-    }
-    int g = 0;
-#endif
+    // fragments of this wave's first tile (its own) of the first batch, and conv2's first row tile
+    X3AFrag cf;
+    load_afrags_x3(cf, s_a + wave * X3_TILE_BYTES, lane);
+    X3W2Row w2r;
+    load_w2_row_mem(w2r, 0, g_w2l, lane16);
+
     int buf = 0;
     for (int ci = 0; ci < ncand; ++ci) {
         const int b = blockIdx.x + ci * stride;
@@ -314,54 +304,87 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) rm[nt] = -INFINITY;
         for (int bt = 0; bt < nbatch; ++bt, buf ^= 1) {
-            const int nt_b = min(X3_BATCH_TILES, ntiles - X3_BATCH_TILES * bt);
-            const int npairs = (nt_b + 1) >> 1;
-            // pair of tiles in front of which this wave's produce step sits: the two waves of a SIMD (w, w + 4) are
-            // two pairs apart
-#ifdef X3_STEP_LO
-            const int step0 = min(wave < 4 ? X3_STEP_LO : X3_STEP_HI, npairs - 1);
-#else
-            const int step0 = min(wave >> 1, npairs - 1);
-#endif
             const char* cur = s_a + buf * X3_BATCH_BYTES;
-            char* nxt = s_a + (buf ^ 1) * X3_BATCH_BYTES;
-            // Software pipeline over the tiles: the fragments of the next tile are in flight during the MFMAs of the
-            // current one.  Behind a produce step the current tile is loaded again, so that no A fragment is live
-            // across the step (it needs the registers).
-            X3_STAMP(g, 0);
-            X3AFrag fA, fB;
-            load_afrags_x3(fA, cur, lane);
+            char* dst = s_a + (buf ^ 1) * X3_BATCH_BYTES + wave * X3_TILE_BYTES;
             f32x4v carry = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            for (int i = 0; i < (nt_b >> 1); ++i) {
-                if (i == step0) {
-                    X3_STAMP(g, 1);
-                    __builtin_amdgcn_s_setprio(X3_PRIO_PRODUCE);
-                    produce_step(nxt);
-                    __builtin_amdgcn_s_setprio(X3_PRIO_CONSUME);
-                    X3_STAMP(g, 2);
-                    load_afrags_x3(fA, cur + (2 * i) * X3_TILE_BYTES, lane);
+            unsigned int keep_h[2] = {0u, 0u}, keep_l[2] = {0u, 0u};       // even row tile of a pair, split and packed
+#pragma unroll
+            for (int t = 0; t < X3_BATCH_TILES; ++t) {
+                // the tile consumed after this one: the wave's own tile of the next batch behind the last step
+                const char* nxt_tile = t + 1 < X3_BATCH_TILES ? cur + ((wave + t + 1) & 7) * X3_TILE_BYTES : dst;
+                // A: chain 0 | the max of the previous tile's last chain, conv2's hi fragments and bias of row tile t
+                X3_FENCE();
+                f32x4v acc0 = mfma_chain12(cf, bwh[0], bwl[0]);
+                rm[NT - 1] = pinned_max(rm[NT - 1], carry);
+                load_w2_row_lds(w2r, t, s_w2, s_b2, lane);
+                X3_SGB_MFMA(1); X3_SGB_VALU(1); X3_SGB_MFMA(1); X3_SGB_VALU(1); X3_SGB_MFMA(1); X3_SGB_DSR(1);
+                X3_SGB_MFMA(1); X3_SGB_DSR(1); X3_SGB_MFMA(1); X3_SGB_DSR(1); X3_SGB_MFMA(7);
+                X3_FENCE();
+                // B: row tile t of layer 2 (a chain of six) | then the lo fragments of the next row tile
+                const f32x4v pacc = l2_row_chain(w2r, hbh, hbl);
+                load_w2_row_mem(w2r, (t + 1) & 7, g_w2l, lane16);
+                X3_SGB_MFMA(6); X3_SGB_VMEM(2);
+                X3_FENCE();
+                unsigned int ph[2], pl[2];
+                if constexpr (NT == 4) {
+                    // C: chain 1 | max of chain 0, split of the row tile's first two values
+                    f32x4v acc1 = mfma_chain12(cf, bwh[1], bwl[1]);
+                    rm[0] = pinned_max(rm[0], acc0);
+                    relu_split2(pacc[0], pacc[1], ph[0], pl[0]);
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) { X3_SGB_MFMA(1); X3_SGB_VALU(1); }
+                    X3_SGB_MFMA(2);
+                    X3_FENCE();
+                    // D: chain 2 | max of chain 1, split of the other two values, the stores of a completed pair
+                    acc0 = mfma_chain12(cf, bwh[2], bwl[2]);
+                    rm[1] = pinned_max(rm[1], acc1);
+                    relu_split2(pacc[2], pacc[3], ph[1], pl[1]);
+                    if (t & 1) {
+                        *(u32x4*)(dst + ((t >> 1) * 64 + lane) * 16) = u32x4{keep_h[0], keep_h[1], ph[0], ph[1]};
+                        *(u32x4*)(dst + X3_PLANE_BYTES + ((t >> 1) * 64 + lane) * 16) = u32x4{keep_l[0], keep_l[1], pl[0], pl[1]};
+                    }
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) { X3_SGB_MFMA(1); X3_SGB_VALU(1); }
+                    if (t & 1) { X3_SGB_MFMA(1); X3_SGB_DSW(1); X3_SGB_MFMA(1); X3_SGB_DSW(1); } else { X3_SGB_MFMA(2); }
+                    X3_FENCE();
+                } else {
+                    relu_split2(pacc[0], pacc[1], ph[0], pl[0]);
+                    relu_split2(pacc[2], pacc[3], ph[1], pl[1]);
+                    if (t & 1) {
+                        *(u32x4*)(dst + ((t >> 1) * 64 + lane) * 16) = u32x4{keep_h[0], keep_h[1], ph[0], ph[1]};
+                        *(u32x4*)(dst + X3_PLANE_BYTES + ((t >> 1) * 64 + lane) * 16) = u32x4{keep_l[0], keep_l[1], pl[0], pl[1]};
+                    }
+                    X3_FENCE();
                 }
-                load_afrags_x3(fB, cur + (2 * i + 1) * X3_TILE_BYTES, lane);
-                consume_tile_x3<NT>(fA, bwh, bwl, carry, rm);
-                load_afrags_x3(fA, cur + min(2 * i + 2, nt_b - 1) * X3_TILE_BYTES, lane);
-                consume_tile_x3<NT>(fB, bwh, bwl, carry, rm);
-            }
-            if (nt_b & 1) {                       // odd tail: fA already holds tile nt_b - 1
-                if ((nt_b >> 1) == step0) {
-                    __builtin_amdgcn_s_setprio(X3_PRIO_PRODUCE);
-                    produce_step(nxt);
-                    __builtin_amdgcn_s_setprio(X3_PRIO_CONSUME);
-                    load_afrags_x3(fA, cur + (nt_b - 1) * X3_TILE_BYTES, lane);
+                if (!(t & 1)) { keep_h[0] = ph[0]; keep_h[1] = ph[1]; keep_l[0] = pl[0]; keep_l[1] = pl[1]; }
+                // E: the last chain; every fragment register is refilled for the next tile as soon as its last MFMA
+                // has been issued (lo plane after four MFMAs, hi plane one by one at the end)
+                f32x4v z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf.l[k], bwh[NT - 1][k], z, 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cf.l[k] = *(const bf16x8*)(nxt_tile + X3_PLANE_BYTES + (k * 64 + lane) * 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf.h[k], bwl[NT - 1][k], z, 0, 0, 0);
+                rm[NT - 2] = pinned_max(rm[NT - 2], acc0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf.h[k], bwh[NT - 1][k], z, 0, 0, 0);
+                    cf.h[k] = *(const bf16x8*)(nxt_tile + (k * 64 + lane) * 16);
                 }
-                consume_tile_x3<NT>(fA, bwh, bwl, carry, rm);
+                X3_SGB_MFMA(4);
+                X3_SGB_MFMA(1); X3_SGB_DSR(1); X3_SGB_MFMA(1); X3_SGB_DSR(1); X3_SGB_MFMA(1); X3_SGB_DSR(1); X3_SGB_MFMA(1); X3_SGB_DSR(1);
+                X3_SGB_VALU(2);
+                X3_SGB_MFMA(1); X3_SGB_DSR(1); X3_SGB_MFMA(1); X3_SGB_DSR(1); X3_SGB_MFMA(1); X3_SGB_DSR(1); X3_SGB_MFMA(1); X3_SGB_DSR(1);
+                X3_FENCE();
+                carry = z;
             }
-            rm[NT - 1] = max3(rm[NT - 1], max3(carry[0], carry[1], carry[2]), carry[3]);
-            X3_STAMP(g, 3);
-            lds_barrier();          // orders the A-fragment buffers only: the point load of the next produce step stays in flight
-            X3_STAMP(g, 4);
-#ifdef PNGPD_STAMPS
-            ++g;
-#endif
+            rm[NT - 1] = pinned_max(rm[NT - 1], carry);
+            // tail of the batch: layer 1 of the tile after next (the fragments of this wave's own tile of the next batch
+            // are already on their way)
+            layer1_x3(px, s_w1f + ltab * W1F_BYTES, ones, lane, hbh, hbl);
+            advance();
+            lds_barrier();
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -372,21 +395,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
             if (q == 0) a.pooled[(size_t)b * C3 + ch] = m;
         }
     }
-#ifdef PNGPD_STAMPS
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-        g_stamp_clock_x3[2] = __builtin_amdgcn_s_memtime();
-        g_stamp_clock_x3[3] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
 }
-
-#ifdef PNGPD_STAMPS
-extern "C" int pngpd_debug_read_stamps_x3(unsigned long long* stamps, unsigned long long* clock) {
-    hipError_t e = hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_stamps_x3), sizeof(g_stamps_x3));
-    if (e != hipSuccess) return (int)e;
-    return (int)hipMemcpyFromSymbol(clock, HIP_SYMBOL(g_stamp_clock_x3), sizeof(g_stamp_clock_x3));
-}
-#endif
 
 hipError_t launch_conv_stack_x3(const ConvStackArgs& a, hipStream_t s) {
     if (a.B < 1 || a.P < 1 || !a.x || !a.w1tab || !a.w2p || !a.w2lo || !a.b2p || !a.w3p || !a.w3lo || !a.b3 || !a.pooled)

@@ -60,8 +60,7 @@ def run(B=4096, P=750):
     waves, nb, ne = 8, 6, 5
     stamps = (ctypes.c_ulonglong * (waves * nb * ne))()
     clock = (ctypes.c_ulonglong * 4)()
-    lib = ctypes.CDLL(DIAG)
-    rc = (lib.pngpd_debug_read_stamps_x3 if PRECISION == "bf16x3" else lib.pngpd_debug_read_stamps)(stamps, clock)
+    rc = lib.pngpd_debug_read_stamps(stamps, clock)
     assert rc == 0, rc
     s = np.array(stamps, dtype=np.int64).reshape(waves, nb, ne)
     cyc, rt = clock[2] - clock[0], clock[3] - clock[1]
