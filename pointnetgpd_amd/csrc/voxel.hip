@@ -68,7 +68,12 @@ VoxelWs carve(void* ws, int n) {
     return w;
 }
 
-__global__ __launch_bounds__(VX_THREADS) void k_vox_minmax(const float* pts, int S, float* partial) {
+// min / max of the points; on the way the occupancy bitmap is cleared (16-byte stores spread over the same
+// workgroups: a fill of its own is one more launch in front of a chain of dependent launches)
+__global__ __launch_bounds__(VX_THREADS) void k_vox_minmax(const float* pts, int S, float* partial, uint4* bitmap4,
+                                                           size_t quads) {
+    for (size_t i = blockIdx.x * (size_t)VX_THREADS + threadIdx.x; i < quads; i += (size_t)gridDim.x * VX_THREADS)
+        bitmap4[i] = make_uint4(0u, 0u, 0u, 0u);
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (long long i = blockIdx.x * (long long)VX_THREADS + threadIdx.x; i < S; i += (long long)gridDim.x * VX_THREADS) {
 #pragma unroll
@@ -264,6 +269,10 @@ __global__ __launch_bounds__(1024) void k_vox_scan(unsigned int* blocksum, int n
     }
 }
 
+struct __attribute__((packed, aligned(4))) VoxRow {
+    float x, y, z;
+};
+
 __global__ __launch_bounds__(VX_THREADS) void k_vox_emit(const unsigned int* bitmap, size_t words,
                                                          const unsigned int* blocksum, const float* mid, int n,
                                                          float* out, long long capacity) {
@@ -276,31 +285,46 @@ __global__ __launch_bounds__(VX_THREADS) void k_vox_emit(const unsigned int* bit
         w[j] = base + j < words ? bitmap[base + j] : 0u;
         c += __popc(w[j]);
     }
-    __shared__ unsigned int s[VX_THREADS];
-    s[threadIdx.x] = c;
-    __syncthreads();
-    for (int off = 1; off < VX_THREADS; off <<= 1) {
-        const unsigned int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-        __syncthreads();
-        s[threadIdx.x] += t;
-        __syncthreads();
+    // exclusive prefix of c over the block: shuffles inside a wave, one barrier for the four wave totals
+    __shared__ unsigned int s_wave[VX_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
     }
-    long long pos = (long long)blocksum[blockIdx.x] + s[threadIdx.x] - c;
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    unsigned int before = 0;
+    for (int k = 0; k < wave; ++k) before += s_wave[k];
+    long long pos = (long long)blocksum[blockIdx.x] + before + inc - c;
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
         unsigned int bits = w[j];
+        if (bits == 0u) continue;
+        // voxel of the word's first bit, by 32-bit divisions once per word (n <= VOXEL_MAX_N keeps every key below
+        // 2^32); the voxel of a set bit follows by stepping along z with carries.  (One 64-bit division pair per set
+        // bit made this kernel 24 us at a million points: the divisions, not the memory, were its cost.)
+        const unsigned int key0 = (unsigned int)(base + j) * 32u, un = (unsigned int)n;
+        const unsigned int r0 = key0 / un;
+        int iz0 = (int)(key0 - r0 * un), iy0 = (int)(r0 % un), ix0 = (int)(r0 / un);
+        int prev = 0;
         while (bits) {
             const int b = __ffs(bits) - 1;
             bits &= bits - 1;
-            const unsigned long long key = (unsigned long long)(base + j) * 32 + b;
-            const int iz = (int)(key % n);
-            const unsigned long long r = key / n;
-            const int iy = (int)(r % n), ix = (int)(r / n);
-            if (pos < capacity) {
-                out[pos * 3 + 0] = mid[ix];
-                out[pos * 3 + 1] = mid[n + iy];
-                out[pos * 3 + 2] = mid[2 * n + iz];
+            iz0 += b - prev;
+            prev = b;
+            while (iz0 >= n) {
+                iz0 -= n;
+                if (++iy0 == n) {
+                    iy0 = 0;
+                    ++ix0;
+                }
             }
+            // a row is one 12-byte store (working the centres out here instead of looking them up is slower: 24 us
+            // against 20 at a million points)
+            if (pos < capacity) *(VoxRow*)(out + pos * 3) = VoxRow{mid[ix0], mid[n + iy0], mid[2 * n + iz0]};
             ++pos;
         }
     }
@@ -310,7 +334,7 @@ __global__ __launch_bounds__(VX_THREADS) void k_vox_emit(const unsigned int* bit
 
 size_t voxel_workspace_bytes(int n) {
     return align256(sizeof(VoxelParams)) + align256((size_t)VX_RED_BLOCKS * 6 * 4) + 2 * align256((size_t)3 * n * 4) +
-           align256((vx_blocks(n) + 1) * 4) + align256(vx_words(n) * 4);
+           align256((vx_blocks(n) + 1) * 4) + align256(vx_words(n) * 4);      // the bitmap: a whole number of 16-byte quads
 }
 
 hipError_t launch_voxel_unique(const float* pts, int S, int n, int f32_edges, void* ws, float* out, long long capacity,
@@ -318,11 +342,10 @@ hipError_t launch_voxel_unique(const float* pts, int S, int n, int f32_edges, vo
     const VoxelWs w = carve(ws, n);
     const size_t words = vx_words(n);
     const int nb = (int)vx_blocks(n);
-    hipError_t e = hipMemsetAsync(w.bitmap, 0, words * 4, s);
-    if (e != hipSuccess) return e;
-    int red_blocks = (S + VX_THREADS - 1) / VX_THREADS;
-    red_blocks = red_blocks < VX_RED_BLOCKS ? red_blocks : VX_RED_BLOCKS;
-    hipLaunchKernelGGL(k_vox_minmax, dim3(red_blocks), dim3(VX_THREADS), 0, s, pts, S, w.partial);
+    // the workspace is caller memory of at least voxel_workspace_bytes(n), whose bitmap region is rounded up to 256 bytes
+    const size_t quads = (words * 4 + 15) / 16;
+    int red_blocks = VX_RED_BLOCKS;          // also clears the bitmap: always the full grid
+    hipLaunchKernelGGL(k_vox_minmax, dim3(red_blocks), dim3(VX_THREADS), 0, s, pts, S, w.partial, (uint4*)w.bitmap, quads);
     hipLaunchKernelGGL(k_vox_setup, dim3(1), dim3(VX_THREADS), 0, s, w.partial, red_blocks, n, f32_edges, w.prm, w.mid,
                        w.canon);
     int mark_blocks = (S + VX_THREADS - 1) / VX_THREADS;

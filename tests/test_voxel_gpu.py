@@ -70,9 +70,19 @@ def test_float32_centres_that_coincide_are_one_row():
 def test_scene_size_and_idempotence():
     pts = synth.scene_points(0, 1_000_000)
     t = torch.from_numpy(pts).cuda()
-    v = voxel.get_voxel_fun(t, 500)
-    want = vo.get_voxel_fun(pts, 500)
+    v = voxel.get_voxel_fun(t, 500)          # default edges: what the numpy installed here makes the reference compute
+    assert voxel.default_edges() == ("float32" if int(np.__version__.split(".")[0]) >= 2 else "float64")
+    want = vo.get_voxel_fun(pts, 500, edges=voxel.default_edges())
     np.testing.assert_array_equal(v.cpu().numpy(), want)
+    # the same call with the count left on the device: same rows, nothing read back, buffers reused
+    buf = torch.full((len(pts), 3), -7.0, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        out, count = voxel.voxel_unique_device(t, 500, out=buf, count=cnt)
+        assert out.data_ptr() == buf.data_ptr() and int(count.item()) == len(want)
+        assert torch.equal(out[:len(want)], v) and bool((out[len(want):] == -7.0).all())
+    for edges in ("float64", "float32"):
+        np.testing.assert_array_equal(voxel.get_voxel_fun(t, 500, edges=edges).cpu().numpy(), vo.get_voxel_fun(pts, 500, edges=edges))
     # the centres of a grid are fixed points of the same grid only if the box does not move; what
     # always holds: a second pass cannot produce more rows than the first, and rows stay sorted
     v2 = voxel.get_voxel_fun(v, 500)
