@@ -215,9 +215,13 @@ __device__ __forceinline__ float pinned_max(float m, const f32x4v& v) {
     return m;
 }
 
+// NT = channel tiles of 16 per wave.  4 is the throughput shape: a workgroup covers 512 channels, grid.y = 2.  A batch
+// too small to give every CU a workgroup runs NT = 2 with grid.y = 4, or NT = 1 with grid.y = 8 (a single candidate,
+// the reference's own call shape).  The arithmetic of a channel does not depend on the cut, so a candidate's result
+// does not depend on the batch it is scored in.
 template <int NT>
 __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs a) {
-    static_assert(NT == 4 || NT == 2, "channel tiles per wave");
+    static_assert(NT == 4 || NT == 2 || NT == 1, "channel tiles per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: scalar branches and addresses
@@ -314,11 +318,14 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
                 const char* nxt_tile = t + 1 < X3_BATCH_TILES ? cur + ((wave + t + 1) & 7) * X3_TILE_BYTES : dst;
                 // A: chain 0 | the max of the previous tile's last chain, conv2's hi fragments and bias of row tile t
                 X3_FENCE();
-                f32x4v acc0 = mfma_chain12(cf, bwh[0], bwl[0]);
+                f32x4v acc0 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (NT >= 2) acc0 = mfma_chain12(cf, bwh[0], bwl[0]);
                 rm[NT - 1] = pinned_max(rm[NT - 1], carry);
                 load_w2_row_lds(w2r, t, s_w2, s_b2, lane);
-                X3_SGB_MFMA(1); X3_SGB_VALU(1); X3_SGB_MFMA(1); X3_SGB_VALU(1); X3_SGB_MFMA(1); X3_SGB_DSR(1);
-                X3_SGB_MFMA(1); X3_SGB_DSR(1); X3_SGB_MFMA(1); X3_SGB_DSR(1); X3_SGB_MFMA(7);
+                if constexpr (NT >= 2) {
+                    X3_SGB_MFMA(1); X3_SGB_VALU(1); X3_SGB_MFMA(1); X3_SGB_VALU(1); X3_SGB_MFMA(1); X3_SGB_DSR(1);
+                    X3_SGB_MFMA(1); X3_SGB_DSR(1); X3_SGB_MFMA(1); X3_SGB_DSR(1); X3_SGB_MFMA(7);
+                }
                 X3_FENCE();
                 // B: row tile t of layer 2 (a chain of six) | then the lo fragments of the next row tile
                 const f32x4v pacc = l2_row_chain(w2r, hbh, hbl);
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
                 for (int k = 0; k < 4; ++k) cf.l[k] = *(const bf16x8*)(nxt_tile + X3_PLANE_BYTES + (k * 64 + lane) * 16);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf.h[k], bwl[NT - 1][k], z, 0, 0, 0);
-                rm[NT - 2] = pinned_max(rm[NT - 2], acc0);
+                if constexpr (NT >= 2) rm[NT - 2] = pinned_max(rm[NT - 2], acc0);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf.h[k], bwh[NT - 1][k], z, 0, 0, 0);
@@ -410,6 +417,7 @@ hipError_t launch_conv_stack_x3(const ConvStackArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3(a.B < per_piece ? a.B : per_piece, pieces), dim3(X3_THREADS), X3_LDS_BYTES, s, a);
         return hipGetLastError();
     };
+    if (a.B * 8 <= n_cu) return launch(conv_stack_x3_kernel<1>, 8);
     if (a.B * 4 <= n_cu) return launch(conv_stack_x3_kernel<2>, 4);
     return launch(conv_stack_x3_kernel<4>, 2);
 }

@@ -15,7 +15,7 @@ P, k = 750, 2
 m = PointNetCls(P, 3, k)
 m.load_state_dict(synth.torch_state_dict(0, k, 0.02))
 m = m.cuda().eval()
-for prec in ("bf16", "fp32"):
+for prec in ("bf16", "bf16x3", "fp32"):
     m.precision = prec
     pc = synth.candidate_points(0, 1, P)[0].T.astype(np.float64).copy()       # [P,3] like the reference's local_pc
     for _ in range(20):
