@@ -36,17 +36,20 @@ __global__ __launch_bounds__(256, 2) void tall_gemm_kernel(const float* __restri
                                                            int w_is_kn, const float* __restrict__ bias,
                                                            float* __restrict__ Y, int M, int relu,
                                                            double* __restrict__ stat_rec) {
-    extern __shared__ __attribute__((aligned(16))) float sB[];      // [K][N]
-    constexpr int NT = N / 32, KH = K / 2;
+    // B rows k < K/2 at k*N, rows k >= K/2 shifted by 32 floats: an MFMA step reads row s for the lanes of half 0 and
+    // row K/2 + s for half 1, 32 consecutive floats each; unshifted, the two rows start on the same LDS bank
+    // (K/2 * N is a multiple of 64 words) and every read is a two-way conflict (1.35 M conflict cycles per launch)
+    extern __shared__ __attribute__((aligned(16))) float sB[];      // [K][N] + 32
+    constexpr int NT = N / 32, KH = K / 2, SHIFT = 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
     if (w_is_kn) {
-        for (int i = tid * 4; i < K * N; i += 1024) *(float4*)(sB + i) = *(const float4*)(W + i);
+        for (int i = tid * 4; i < K * N; i += 1024) *(float4*)(sB + i + (i >= KH * N ? SHIFT : 0)) = *(const float4*)(W + i);
     } else {                                   // W[N][K] -> B[k][n]
         for (int i = tid; i < K * N; i += 256) {
             const int n = i / K, k = i - n * K;
-            sB[k * N + n] = W[i];
+            sB[k * N + n + (k >= KH ? SHIFT : 0)] = W[i];
         }
     }
     __syncthreads();
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void tall_gemm_kernel(const float* __restri
             const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float* brow = sB + (h * KH + 4 * q + e) * N + r;
+                const float* brow = sB + (h * KH + 4 * q + e) * N + h * SHIFT + r;
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], brow[32 * t], acc[t], 0, 0, 0);
@@ -208,7 +211,7 @@ template <int K, int N>
 static hipError_t launch_one(const float* X, const float* W, int w_is_kn, const float* bias, float* Y, int M, int relu,
                              double* stat_rec, int blocks, hipStream_t s) {
     auto kern = tall_gemm_kernel<K, N>;
-    size_t lds = (size_t)K * N * sizeof(float);
+    size_t lds = ((size_t)K * N + 32) * sizeof(float);
     const size_t red = (size_t)8 * N * 3 * sizeof(double);
     if (lds < red) lds = red;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -241,10 +241,15 @@ def test_config3_full_size_p500_sharded_batch():
         part, part_t = m(x[lo:hi].contiguous())
         assert torch.equal(part, logp[lo:hi]) and torch.equal(part_t, trans[lo:hi])
     oracle = po.build_cls(P, 2, synth.torch_state_dict(seed, 2, 0.02, 1.7))
-    idx = torch.tensor([0, 12_345, B - 1], device="cuda")
+    pick = torch.randperm(B, generator=torch.Generator().manual_seed(seed))[:253]
+    idx = torch.cat([torch.tensor([0, 12_345, B - 1]), pick]).cuda()          # 256 rows spread over the whole batch
     with torch.no_grad():
-        ref, _ = oracle(x[idx].cpu())
+        ref, ref_t = oracle(x[idx].cpu())
     assert (logp[idx].cpu() - ref).abs().max().item() <= BF16_ATOL
+    # the same rows in the float32-grade default mode, scored as a batch of their own
+    m.precision = "bf16x3"
+    sub, sub_t = m(x[idx].contiguous())
+    assert (sub.cpu() - ref).abs().max().item() <= X3_ATOL and (sub_t.cpu() - ref_t).abs().max().item() <= X3_ATOL
 
 
 def test_p1000_full_view_variant():
