@@ -24,6 +24,15 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 
 typedef f32x4 f32x4v;
 
+// Running maximum over one accumulator, as two v_max3.  The empty asm makes the result opaque: in an unrolled batch
+// the compiler otherwise re-associates the maxima of all tiles into one tree at the end of the batch and keeps
+// every accumulator alive (in scratch memory) until then.
+__device__ __forceinline__ float pinned_max(float m, const f32x4v& v) {
+    m = max3(m, max3(v[0], v[1], v[2]), v[3]);
+    asm volatile("" : "+v"(m));
+    return m;
+}
+
 // Orders this wave's own LDS accesses (a wave-private table is written, later read, by one wave).
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -206,15 +206,6 @@ __device__ __forceinline__ void produce_tile_x3(float px, const char* s_w1f, uns
     }
 }
 
-// Running maximum over one accumulator, as two v_max3.  The empty asm makes the result opaque: in the unrolled batch
-// the compiler otherwise re-associates the maxima of all tiles into one tree at the end of the batch and keeps
-// every accumulator alive (in scratch memory) until then.
-__device__ __forceinline__ float pinned_max(float m, const f32x4v& v) {
-    m = max3(m, max3(v[0], v[1], v[2]), v[3]);
-    asm volatile("" : "+v"(m));
-    return m;
-}
-
 // NT = channel tiles of 16 per wave.  4 is the throughput shape: a workgroup covers 512 channels, grid.y = 2.  A batch
 // too small to give every CU a workgroup runs NT = 2 with grid.y = 4, or NT = 1 with grid.y = 8 (a single candidate,
 // the reference's own call shape).  The arithmetic of a channel does not depend on the cut, so a candidate's result

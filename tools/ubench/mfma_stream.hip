@@ -194,11 +194,18 @@ __device__ __forceinline__ void consume(const bf16x8 (&af)[4], const bf16x8 (&bw
     carry = accA;
 }
 
-template <int V>
+// PR: how the two waves of a SIMD share the matrix pipe.  0: nothing  1: waves 4-7 at priority 3
+//     2: the favoured wave changes with bit 11 of the shader clock  3: the wave that is behind its partner (progress
+//     words in LDS, written and read once per tile pair) gets priority
+template <int V, int PR = 0>
 __global__ __launch_bounds__(512) void k_loop(const bf16x8* wsrc, const bf16x8* asrc, float* out,
                                               unsigned long long* cyc, int iters) {
     __shared__ bf16x8 s_a[16 * 4 * 64];        // 16 tiles of A fragments
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int s_prog[8];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < 8) s_prog[threadIdx.x] = 0;
+    if (PR == 1 && wave >= 4) __builtin_amdgcn_s_setprio(3);
+    int prog = 0;
     for (int i = threadIdx.x; i < 16 * 4 * 64; i += blockDim.x) s_a[i] = asrc[i & 255];
     __syncthreads();
     bf16x8 bw[8][4];
@@ -216,6 +223,16 @@ __global__ __launch_bounds__(512) void k_loop(const bf16x8* wsrc, const bf16x8* 
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         for (int i = 0; i < 8; ++i) {
+            if (PR == 2) {
+                const int fav = (int)((__builtin_amdgcn_s_memtime() >> 11) & 1) ^ (wave >> 2);
+                if (fav) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+            }
+            if (PR == 3) {
+                ++prog;
+                const int other = __builtin_amdgcn_readfirstlane(((volatile int*)s_prog)[wave ^ 4]);
+                ((volatile int*)s_prog)[wave] = prog;
+                if (other > prog || (other == prog && wave >= 4)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+            }
             if (!(V & 1) && V != 4) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) afB[k] = s_a[((2 * i + 1) * 4 + k) * 64 + lane];
@@ -237,23 +254,28 @@ __global__ __launch_bounds__(512) void k_loop(const bf16x8* wsrc, const bf16x8* 
     float r = carry[0];
 #pragma unroll
     for (int n = 0; n < 8; ++n) r += rm[n];
-    out[blockIdx.x * 256 + threadIdx.x] = r;
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
-    (void)wave;
+    out[blockIdx.x * 512 + threadIdx.x] = r;
+    if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
-template <int V>
-static void run_loop(const char* name, const bf16x8* w, const bf16x8* a, float* out, unsigned long long* cyc, int blocks) {
+template <int V, int PR = 0>
+static void run_loop(const char* name, const bf16x8* w, const bf16x8* a, float* out, unsigned long long* cyc, int blocks,
+                     int threads = 256) {
     const int iters = 250;                    // x 16 tiles x 32 MFMAs
+    const int waves = threads / 64;
     for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL(k_loop<V>, dim3(blocks), dim3(256), 0, 0, w, a, out, cyc, iters);
+        hipLaunchKernelGGL((k_loop<V, PR>), dim3(blocks), dim3(threads), 0, 0, w, a, out, cyc, iters);
         hipDeviceSynchronize();
-        std::vector<unsigned long long> h(blocks);
-        hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost);
-        double mean = 0;
-        for (auto v : h) mean += (double)v;
-        mean /= blocks;
-        printf("%-36s rep %d: %.2f ticks/MFMA (%.0f per tile)\n", name, rep, mean / (iters * 16 * 32.0), mean / (iters * 16.0));
+        std::vector<unsigned long long> h(blocks * 8);
+        hipMemcpy(h.data(), cyc, blocks * 8 * 8, hipMemcpyDeviceToHost);
+        double lo = 0, hi = 0;                // waves 0-3 / waves 4-7 (the second wave of each SIMD)
+        for (int b = 0; b < blocks; ++b)
+            for (int wv = 0; wv < waves; ++wv) (wv < 4 ? lo : hi) += (double)h[b * 8 + wv];
+        lo /= blocks * 4;
+        hi /= blocks * (waves > 4 ? waves - 4 : 1);
+        const double per_simd = (waves > 4 ? (hi > lo ? hi : lo) / 2 : lo) / (iters * 16 * 32.0);
+        printf("%-36s %d waves rep %d: waves 0-3 %.2f, waves 4-7 %.2f ticks per own MFMA; %.2f ticks/MFMA per SIMD\n", name,
+               waves, rep, lo / (iters * 16 * 32.0), hi / (iters * 16 * 32.0), per_simd);
     }
 }
 
@@ -292,8 +314,8 @@ int main() {
     unsigned long long* cyc;
     hipMalloc(&w, hw.size() * 2);
     hipMalloc(&a, ha.size() * 2);
-    hipMalloc(&out, blocks * 256 * 4);
-    hipMalloc(&cyc, blocks * 8);
+    hipMalloc(&out, blocks * 512 * 4);
+    hipMalloc(&cyc, blocks * 8 * 8);
     hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(a, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
     run<0>("8 chains, B = 32 fragments", w, a, out, cyc, blocks);
@@ -315,5 +337,11 @@ int main() {
     run_loop<4>("consume loop, LDS read inside chain", w, a, out, cyc, blocks);
     run_loop<2>("consume loop, no max3", w, a, out, cyc, blocks);
     run_loop<3>("consume loop, no max3, no LDS", w, a, out, cyc, blocks);
+    run_loop<0>("consume loop as in the kernel", w, a, out, cyc, blocks, 512);
+    run_loop<1>("consume loop, no LDS reads", w, a, out, cyc, blocks, 512);
+    run_loop<4>("consume loop, LDS read inside chain", w, a, out, cyc, blocks, 512);
+    run_loop<0, 1>("kernel loop, waves 4-7 prio 3", w, a, out, cyc, blocks, 512);
+    run_loop<0, 2>("kernel loop, prio by clock bit 11", w, a, out, cyc, blocks, 512);
+    run_loop<0, 3>("kernel loop, prio to the one behind", w, a, out, cyc, blocks, 512);
     return 0;
 }
