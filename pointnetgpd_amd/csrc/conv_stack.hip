@@ -23,9 +23,6 @@
 // f32 path:  one workgroup per candidate, W3 streamed through LDS, v_mfma_f32_32x32x2_f32.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-#include <type_traits>
-
 #include "conv_stack_common.h"
 #include "kernels.h"
 #include "pngpd.h"
@@ -143,8 +140,7 @@ constexpr int WS_OFF_B2 = WS_OFF_W2 + (int)W2P_BF16_BYTES;
 constexpr int WS_OFF_W1B = WS_OFF_B2 + C2 * 4;             // BN-folded conv1 table, shared
 constexpr int WS_OFF_W1 = WS_OFF_W1B + C1 * 16;            // layer-1 A fragments of two candidates (2 x W1F_BYTES)
 constexpr int WS_OFF_B3 = WS_OFF_W1 + 2 * 4096;            // conv3 bias: read once per candidate by every wave
-constexpr int WS_OFF_PROG = WS_OFF_B3 + C3 * 4;            // woven kernel: progress word of each wave
-constexpr int WS_LDS_BYTES = WS_OFF_PROG + WS_WAVES * 4;
+constexpr int WS_LDS_BYTES = WS_OFF_B3 + C3 * 4;
 
 // Layer 1 (3 -> 64, K = 3 plus the bias) also runs on the matrix pipe, as ONE v_mfma_f32_16x16x32_bf16 per tile of
 // 16 channels x 16 points, at float32 accuracy: every float is cut into three bf16 pieces by truncation,
@@ -471,251 +467,6 @@ extern "C" int pngpd_debug_read_stamps(unsigned long long* stamps, unsigned long
 #endif
 
 // ------------------------------------------------------------------------------------------
-// Woven form of the throughput shape (8 channel tiles per wave, full batches of 16 tiles).
-//
-// In conv_stack_bf16_kernel a wave leaves the consume loop once per batch for a produce step of ~270 vector / LDS
-// instructions and 40 MFMAs; during that step its SIMD partner has the matrix pipe to itself and does not fill it.
-// Here a wave runs ONE instruction stream: the produce work of its two tiles of the next batch is cut into pieces
-// that sit in the gaps between the MFMA chains of the consume loop -
-//     tile step 0      layer 1 of both tiles (4 LDS reads, the piece split of the coordinates, 8 MFMAs, 4 relu/packs)
-//     tile steps 1..8  layer 2, one (tile, k-step of layer 3) per step: 6 LDS reads, 4 MFMAs, one relu/pack, one store
-//     tile step 9      cursor to the batch after next, its points requested from memory
-//     batch tail       wave 0 folds the next candidate's 3x3 into the layer-1 table when the cursor enters a candidate
-// - so no wave is ever away from the matrix pipe for longer than four MFMAs.  A batch always runs 16 tiles (rows beyond
-// P repeat the last point, which cannot change a maximum); the launcher picks this kernel when that padding is below
-// 10 % of the rows.  A wave consumes the tiles of a batch starting with its own two, whose fragments it requests before
-// the barrier that publishes the batch.  The arithmetic of every channel is that of conv_stack_bf16_kernel, instruction
-// for instruction, so the two kernels return identical bits.
-// ------------------------------------------------------------------------------------------
-#define WV_FENCE() __builtin_amdgcn_sched_barrier(0)
-#ifdef PNGPD_STAMPS
-constexpr int WSTAMP_EVENTS = 18;          // 16 step starts, batch end, behind the barrier
-__device__ unsigned long long g_wstamps[WS_WAVES][STAMP_BATCHES * WSTAMP_EVENTS];
-#define WSTAMP(g, ev)                                                                         \
-    do {                                                                                      \
-        if (blockIdx.x == 0 && lane == 0 && (g) >= STAMP_FIRST_BATCH &&                        \
-            (g) < STAMP_FIRST_BATCH + STAMP_BATCHES)                                          \
-            g_wstamps[wave][((g)-STAMP_FIRST_BATCH) * WSTAMP_EVENTS + (ev)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-extern "C" int pngpd_debug_read_wstamps(unsigned long long* stamps) {
-    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_wstamps), sizeof(g_wstamps));
-}
-#else
-#define WSTAMP(g, ev)
-#endif
-
-__global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_woven_kernel(ConvStackArgs a) {
-    constexpr int NT = 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, q = lane >> 4;
-
-    char* s_a = smem;
-    char* s_w2 = smem + WS_OFF_W2;
-    float* s_b2 = (float*)(smem + WS_OFF_B2);
-    float4* s_w1base = (float4*)(smem + WS_OFF_W1B);
-    char* s_w1f = smem + WS_OFF_W1;
-    float* s_b3 = (float*)(smem + WS_OFF_B3);
-    int* s_prog = (int*)(smem + WS_OFF_PROG);
-    const unsigned int ones = q == 0 ? 0x3f803f80u : q == 1 ? 0x00003f80u : 0u;
-    if (tid < WS_WAVES) s_prog[tid] = 0;
-
-    const int ct0 = wave * NT;
-    bf16x8 bw[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            bw[nt][ks] = *(const bf16x8*)((const char*)a.w3p + ((((ct0 + nt) * 4 + ks) * 64) + lane) * 16);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int piece = wave * 2 + i;
-        dma_piece((const char*)a.w2p + piece * 1024, s_w2 + piece * 1024, lane);
-    }
-    if (tid < C2) s_b2[tid] = a.b2p[tid];
-    if (tid < C1) s_w1base[tid] = a.w1tab[tid];
-    for (int i = tid; i < C3; i += WS_THREADS) s_b3[i] = a.b3[i];
-    if (tid < 2 * 4 * 16)
-        *(u32x4*)(s_w1f + (tid >> 6) * W1F_BYTES + ((((tid >> 4) & 3) * 4 + 3) * 16 + (tid & 15)) * 16) = u32x4{0u, 0u, 0u, 0u};
-    lds_dma_wait();
-    __syncthreads();
-
-    const int ntiles = (a.P + 15) >> 4;
-    const int nbatch = (ntiles + W16_BATCH_TILES - 1) / W16_BATCH_TILES;
-    const int stride = gridDim.x;
-    const int ncand = (a.B - (int)blockIdx.x + stride - 1) / stride;
-
-    // Produce cursor: the (candidate, batch) whose two tiles get their layer 1 NEXT (at step 0 of the coming batch);
-    // px holds this lane's coordinate of their points.  When the cursor enters a candidate, wave 0 writes that
-    // candidate's layer-1 table into the slot the candidate before it does not use - before the barrier in front of
-    // the step 0 that reads it, and after the barrier behind the last step 0 that read the slot's previous owner.
-    int pb = blockIdx.x, pbt = 0, ptab = 0;
-    const int first_tile = 2 * wave;
-    TilePoints px;
-    auto advance = [&]() {
-        if (++pbt == nbatch) {
-            pbt = 0;
-            pb += stride;
-            ptab ^= 1;
-        }
-    };
-    auto fold_if_entered = [&]() {
-        if (wave == 0 && pbt == 0 && pb < a.B) fold_w1_frags(a, pb, s_w1base, s_w1f + ptab * W1F_BYTES, lane);
-    };
-    auto fetch_points = [&]() {
-        if (pb < a.B) load_tile_points(a, pb, pbt * W16_BATCH_TILES + first_tile, c, q, px);
-    };
-    // prologue: the first batch is produced outright
-    fold_if_entered();
-    fetch_points();
-    __syncthreads();
-    produce_tiles(px, s_w1f, ones, s_w2, s_b2, s_a + first_tile * W16_TILE_BYTES, lane);
-    advance();
-    fold_if_entered();
-    fetch_points();
-    bf16x8 afA[4], afB[4];
-    load_afrags(afA, s_a + first_tile * W16_TILE_BYTES, lane);       // this wave's own tile: LDS keeps a wave's order
-    __syncthreads();
-
-    f32x4v carry = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int buf = 0, gstep = 1;             // gstep: tile steps this wave has begun, over the whole kernel
-#ifdef PNGPD_STAMPS
-    int g = 0;
-#endif
-    for (int ci = 0; ci < ncand; ++ci) {
-        const int b = blockIdx.x + ci * stride;
-        float rm[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) rm[nt] = -INFINITY;
-        for (int bt = 0; bt < nbatch; ++bt, buf ^= 1) {
-            const char* cur = s_a + buf * WS_BATCH_BYTES;
-            char* dst = s_a + (buf ^ 1) * WS_BATCH_BYTES + first_tile * W16_TILE_BYTES;
-            const char* w1f_tab = s_w1f + ptab * W1F_BYTES;
-            bf16x8 hb[2][2];            // layer-1 output of the two tiles: layer 2's B operand, [tile][k-step]
-            bf16x8 xb[2];               // layer 1's B operand of the two tiles
-            bf16x8 w1f[4];
-            f32x4v h1[2][2];
-            L2Frags fr;
-            f32x4v pacc[2];
-
-            // the produce piece that follows chain n of tile step t
-            auto piece = [&](auto tc, auto nc) {
-                constexpr int t = decltype(tc)::value, n = decltype(nc)::value;
-                if constexpr (t == 0) {
-                    if constexpr (n == 0) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) w1f[i] = *(const bf16x8*)(w1f_tab + (i * 64 + lane) * 16);
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const unsigned int x = f2u(px.x[u]);
-                            const float r1 = px.x[u] - u2f(x & 0xffff0000u);
-                            const unsigned int m = f2u(r1);
-                            const unsigned int l = f2u(r1 - u2f(m & 0xffff0000u));
-                            u32x4 v;
-                            v[0] = __builtin_amdgcn_perm(x, x, 0x03020302u);
-                            v[1] = __builtin_amdgcn_perm(x, m, 0x07060302u);
-                            v[2] = __builtin_amdgcn_perm(l, m, 0x07060302u);
-                            v[3] = ones;
-                            xb[u] = __builtin_bit_cast(bf16x8, v);
-                        }
-                    } else if constexpr (n == 2 || n == 4) {
-                        constexpr int s = (n - 2) >> 1;
-                        const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            h1[u][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[2 * s], xb[u], zero, 0, 0, 0);
-                            h1[u][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[2 * s + 1], xb[u], zero, 0, 0, 0);
-                        }
-                    } else if constexpr (n == 3 || n == 5) {
-                        constexpr int s = (n - 3) >> 1;
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) hb[u][s] = relu_pack(h1[u][0], h1[u][1]);
-                    }
-                } else if constexpr (t <= 8) {
-                    constexpr int u = (t - 1) >> 2, ks = (t - 1) & 3;
-                    if constexpr (n == 0) {
-                        load_l2frags(fr, ks, s_w2, s_b2, lane);
-                    } else if constexpr (n == 3) {
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) pacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr.wf[tt][0], hb[u][0], fr.bias[tt], 0, 0, 0);
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) pacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr.wf[tt][1], hb[u][1], pacc[tt], 0, 0, 0);
-                    } else if constexpr (n == 5) {
-                        *(bf16x8*)(dst + u * W16_TILE_BYTES + (ks * 64 + lane) * 16) = relu_pack(pacc[0], pacc[1]);
-                    }
-                } else if constexpr (t == 9) {
-                    if constexpr (n == 0) {
-                        advance();
-                        fetch_points();
-                    }
-                }
-            };
-            auto step = [&](auto tc, const bf16x8 (&af)[4], bf16x8 (&afn)[4]) {
-                constexpr int t = decltype(tc)::value;
-                // the tile consumed after this one; behind the last step it is this wave's own first tile of the next batch
-                const char* ntile = t + 1 < W16_BATCH_TILES ? cur + ((first_tile + t + 1) & (W16_BATCH_TILES - 1)) * W16_TILE_BYTES : dst;
-                WV_FENCE();
-                WSTAMP(g, t);
-                // progress words: this wave has reached step `gstep + t`; its SIMD partner's count comes back later
-                __hip_atomic_store(s_prog + wave, gstep + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int partner_at = __hip_atomic_load(s_prog + (wave ^ 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                load_afrags(afn, ntile, lane);
-                WV_FENCE();
-                f32x4v accA = carry, accB;
-#define WV_PAIR(n)                                                                            \
-                accB = mfma_chain4(af, bw[n]);                                                \
-                WV_FENCE();                                                                   \
-                rm[(n + NT - 1) & (NT - 1)] = pinned_max(rm[(n + NT - 1) & (NT - 1)], accA);  \
-                piece(tc, std::integral_constant<int, n>{});                                  \
-                WV_FENCE();                                                                   \
-                accA = mfma_chain4(af, bw[n + 1]);                                            \
-                WV_FENCE();                                                                   \
-                rm[n] = pinned_max(rm[n], accB);                                              \
-                piece(tc, std::integral_constant<int, n + 1>{});                              \
-                WV_FENCE();
-                WV_PAIR(0)
-                {
-                    // The matrix pipe's arbiter serves the older wave of a SIMD first: left alone, waves 0-3 take ~3/4
-                    // of the pipe, reach the batch barrier a third of a batch early, and waves 4-7 finish alone at the
-                    // lone-wave rate.  The wave that is behind its partner therefore raises its priority.
-                    const int p_at = __builtin_amdgcn_readfirstlane(partner_at);
-                    if (p_at > gstep + t || (p_at == gstep + t && wave >= 4)) __builtin_amdgcn_s_setprio(3);
-                    else __builtin_amdgcn_s_setprio(0);
-                }
-                WV_FENCE();
-                WV_PAIR(2)
-                WV_PAIR(4)
-                WV_PAIR(6)
-#undef WV_PAIR
-                carry = accA;
-            };
-#define WV_STEP2(t) step(std::integral_constant<int, t>{}, afA, afB); step(std::integral_constant<int, t + 1>{}, afB, afA);
-            WV_STEP2(0) WV_STEP2(2) WV_STEP2(4) WV_STEP2(6) WV_STEP2(8) WV_STEP2(10) WV_STEP2(12) WV_STEP2(14)
-#undef WV_STEP2
-            fold_if_entered();
-            gstep += W16_BATCH_TILES;
-            WSTAMP(g, 16);
-            lds_barrier();
-            WSTAMP(g, 17);
-#ifdef PNGPD_STAMPS
-            ++g;
-#endif
-        }
-        rm[NT - 1] = pinned_max(rm[NT - 1], carry);
-        carry = f32x4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int ch = wave * (16 * NT) + nt * 16 + c;
-            float m = __builtin_fmaxf(rm[nt], __shfl_xor(rm[nt], 16));
-            m = __builtin_fmaxf(m, __shfl_xor(m, 32)) + s_b3[ch];
-            if (a.relu_out) m = __builtin_fmaxf(m, 0.f);
-            if (q == 0) a.pooled[(size_t)b * C3 + ch] = m;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // exact-f32 MFMA path (v_mfma_f32_32x32x2_f32): every product is an f32 fma chain.
 // LDS: [0,16K) two W3 half-tile buffers (8 KiB) | [16K,48K) W2 fragments | conv1 table |
 //      conv2 bias | per-wave running maxima.
@@ -886,13 +637,6 @@ hipError_t launch_conv_stack_bf16(const ConvStackArgs& a, hipStream_t s) {
     };
     if (a.B * 4 <= n_cu) return launch(conv_stack_bf16_kernel<2>, 4);
     if (a.B * 2 <= n_cu) return launch(conv_stack_bf16_kernel<4>, 2);
-    // experiment, not the default (measured 1-3 % slower than the phase kernel): PNGPD_CONV_STACK_BF16=woven selects the
-    // woven kernel, which always runs whole batches of 16 tiles, when that pads the rows by less than a tenth
-    const int ntiles = (a.P + 15) >> 4;
-    const int padded = (ntiles + W16_BATCH_TILES - 1) / W16_BATCH_TILES * W16_BATCH_TILES;
-    const char* form = getenv("PNGPD_CONV_STACK_BF16");
-    const bool woven = form != nullptr && form[0] == 'w';
-    if (woven && padded * 10 <= ntiles * 11) return launch(conv_stack_bf16_woven_kernel, 1);
     return launch(conv_stack_bf16_kernel<8>, 1);
 }
 
