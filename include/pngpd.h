@@ -121,8 +121,9 @@ int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, in
 /*
  * pngpd_forward_infer without a workspace argument and without any allocation.  It has no counterpart in the
  * reference; it is for callers that cannot allocate device memory: code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc.  The per-batch intermediates (11.3 KB per candidate) live in a device
- * array inside the library, PNGPD_NOALLOC_MAX_B * 11.3 KB = 2.9 MB, which every GPU the library runs on holds
+ * loops, harnesses that forbid hipMalloc.  The per-batch intermediates (11.3 KB per candidate, plus 256 KB for the
+ * partial maxima of batches of at most 8 candidates, whose conv stacks are also cut over points) live in a device
+ * array inside the library, PNGPD_NOALLOC_MAX_B * 11.3 KB + 256 KB = 3.2 MB, which every GPU the library runs on holds
  * until the process ends; its address is looked up once per device in pngpd_model_create.  The call itself
  * allocates and frees nothing.  Same arguments, kernels and results (bit for bit) as pngpd_forward_infer;
  * B > PNGPD_NOALLOC_MAX_B returns PNGPD_ERR_SHAPE.  All calls on one GPU share the one array, so two forwards

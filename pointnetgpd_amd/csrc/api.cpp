@@ -140,10 +140,16 @@ int load_fc(const float* const* t, int u_fc1, int n_last, FcDev& d,
 
 size_t round4(size_t n) { return (n + 3) & ~(size_t)3; }
 
+// Floats of the area that holds the partial maxima of a conv stack cut over points (small batches only); part of
+// every workspace so that its size grows monotonically with B.
+constexpr size_t workspace_part_floats(int B) {
+    return (size_t)pngpd::CONV_SPLIT_MAX_GROUPS * 1024 * (size_t)(B < pngpd::CONV_SPLIT_MAX_B ? B : pngpd::CONV_SPLIT_MAX_B);
+}
+
 struct Workspace {
-    float *pooled, *h512, *h256, *trans, *feat;
+    float *pooled, *h512, *h256, *trans, *feat, *part;
     static size_t floats(int B) {
-        return (size_t)B * (1024 + 512 + 256 + 1024) + round4((size_t)B * 9);
+        return (size_t)B * (1024 + 512 + 256 + 1024) + round4((size_t)B * 9) + workspace_part_floats(B);
     }
     Workspace(void* base, int B) {
         float* p = (float*)base;
@@ -151,15 +157,19 @@ struct Workspace {
         h512 = p;   p += (size_t)B * 512;
         h256 = p;   p += (size_t)B * 256;
         feat = p;   p += (size_t)B * 1024;
-        trans = p;
+        trans = p;  p += round4((size_t)B * 9);
+        part = p;
     }
 };
 
+// groups > 1: `in` is [groups][B][1024] partial maxima; the first layer merges them (and stores the merged rows to
+// `merged` when given).
 int run_fc_chain(const FcDev& fc, const float* in, Workspace& ws, float* out, int B, int tail, int precision,
-                 hipStream_t s) {
+                 hipStream_t s, int groups = 1, float* merged = nullptr) {
     if (precision != PNGPD_FP32) {
         // split-bf16 products: f32-grade results on the bf16 matrix pipe
-        HIP_TRY(pngpd::launch_fc_bf16x3(in, fc.wsplit[0].p, (const float*)fc.b[0].p, ws.h512, B, fc.n[0], fc.k[0], 1, s));
+        HIP_TRY(pngpd::launch_fc_bf16x3(in, fc.wsplit[0].p, (const float*)fc.b[0].p, ws.h512, B, fc.n[0], fc.k[0], 1, s,
+                                        groups, merged));
         HIP_TRY(pngpd::launch_fc_bf16x3(ws.h512, fc.wsplit[1].p, (const float*)fc.b[1].p, ws.h256, B, fc.n[1], fc.k[1],
                                         1, s));
     } else {
@@ -205,7 +215,8 @@ pngpd::ConvStackArgs stack_args(const StackDev& d, int precision, const float* x
 // code the array's name is only a handle for hipGetSymbolAddress, never a device address.
 static_assert(PNGPD_NOALLOC_MAX_B >= 1, "PNGPD_NOALLOC_MAX_B");
 static constexpr size_t SCRATCH_FLOATS =
-    (size_t)PNGPD_NOALLOC_MAX_B * (1024 + 512 + 256 + 1024) + (((size_t)PNGPD_NOALLOC_MAX_B * 9 + 3) & ~(size_t)3);
+    (size_t)PNGPD_NOALLOC_MAX_B * (1024 + 512 + 256 + 1024) + (((size_t)PNGPD_NOALLOC_MAX_B * 9 + 3) & ~(size_t)3) +
+    workspace_part_floats(PNGPD_NOALLOC_MAX_B);
 static __device__ __align__(256) float scratch[SCRATCH_FLOATS];
 
 namespace {
@@ -376,22 +387,43 @@ static int forward_impl(const pngpd_model* m, const float* x_dev, int layout, in
 
     // STN3d: conv stack (ReLU after the max), then the 1024-512-256-9 regressor + identity
     float* trans = trans_dev ? trans_dev : ws.trans;
+    // A batch of a few candidates (the reference scores ONE per call, main_test.py:73-83) cannot fill the chip with
+    // one workgroup per candidate and channel piece: the conv stacks then also cut the points of a candidate into
+    // groups, and the FC layer behind each stack takes the maximum over the groups' partial maxima.
+    int groups = 1, tiles_per_group = 0;
+    HIP_TRY(pngpd::conv_stack_point_groups(precision, B, P, &groups, &tiles_per_group));
+    auto split_args = [&](pngpd::ConvStackArgs a) {
+        a.point_groups = groups;
+        a.tiles_per_group = tiles_per_group;
+        a.pooled = ws.part;
+        return a;
+    };
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
-    HIP_TRY(launch_stack(stack_args(m->stn, precision, x_dev, layout, B, P, nullptr, ws.pooled, 1), s));
+    if (groups > 1)
+        HIP_TRY(launch_stack(split_args(stack_args(m->stn, precision, x_dev, layout, B, P, nullptr, ws.pooled, 1)), s));
+    else
+        HIP_TRY(launch_stack(stack_args(m->stn, precision, x_dev, layout, B, P, nullptr, ws.pooled, 1), s));
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-    int rc = run_fc_chain(m->stn_fc, ws.pooled, ws, trans, B, pngpd::FC_TAIL_ADD_IDENTITY, precision, s);
+    int rc = run_fc_chain(m->stn_fc, groups > 1 ? ws.part : ws.pooled, ws, trans, B, pngpd::FC_TAIL_ADD_IDENTITY, precision,
+                          s, groups);
     if (rc) return rc;
     if (!(m->parts & PNGPD_PART_TRUNK)) return PNGPD_OK;
 
     // PointNetfeat: points times trans, conv stack without the last ReLU
     float* feat = feat_dev ? feat_dev : ws.feat;
+    const bool head = (m->parts & PNGPD_PART_HEAD) && logp_dev;
+    if (!head) groups = 1;                               // no FC layer behind the trunk to merge the groups
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
-    HIP_TRY(launch_stack(stack_args(m->trunk, precision, x_dev, layout, B, P, trans, feat, 0), s));
+    if (groups > 1)
+        HIP_TRY(launch_stack(split_args(stack_args(m->trunk, precision, x_dev, layout, B, P, trans, feat, 0)), s));
+    else
+        HIP_TRY(launch_stack(stack_args(m->trunk, precision, x_dev, layout, B, P, trans, feat, 0), s));
     if (ev) HIP_TRY(hipEventRecord(ev[3], s));
-    if (!(m->parts & PNGPD_PART_HEAD) || !logp_dev) return PNGPD_OK;
+    if (!head) return PNGPD_OK;
 
-    // PointNetCls head + log_softmax
-    return run_fc_chain(m->head_fc, feat, ws, logp_dev, B, pngpd::FC_TAIL_LOG_SOFTMAX, precision, s);
+    // PointNetCls head + log_softmax (the merged global feature goes to `feat` on the way)
+    return run_fc_chain(m->head_fc, groups > 1 ? ws.part : feat, ws, logp_dev, B, pngpd::FC_TAIL_LOG_SOFTMAX, precision, s,
+                        groups, groups > 1 ? feat : nullptr);
 }
 
 int pngpd_forward_infer(const pngpd_model* m, const float* x_dev, int layout, int B, int P,

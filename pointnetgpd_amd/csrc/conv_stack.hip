@@ -303,9 +303,13 @@ __device__ __forceinline__ int piece_of() {
 // NT = channel tiles of 16 per wave: 8 is the throughput shape (a workgroup covers all 1024 channels, grid.y = 1).
 // A batch too small to give every CU a candidate runs NT = 2 with grid.y = 4: workgroup (x, y) covers channels
 // [256y, 256y + 256) and repeats layers 1-2; the arithmetic of a channel does not depend on the cut.
-template <int NT>
+// SPLIT (small batches only): grid.z cuts the POINTS of a candidate into groups of a.tiles_per_group tiles as well;
+// workgroup (x, y, z) writes the maxima over its group to pooled + z * B * 1024 (bias and ReLU applied: both commute
+// with a maximum, bit for bit), and the layer that reads them takes the maximum over the groups.
+template <int NT, bool SPLIT = false>
 __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackArgs a) {
     static_assert(NT == 8 || NT == 4 || NT == 2, "channel tiles per wave");
+    static_assert(!(SPLIT && NT == 8), "the throughput shape is never cut over points");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // wave-uniform, and said so: branches on it become scalar branches and its address arithmetic scalar registers
@@ -343,10 +347,13 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
     lds_dma_wait();
     __syncthreads();
 
-    const int ntiles = (a.P + 15) >> 4;
+    // this workgroup's tiles: [tile_base, tile_base + ntiles)
+    const int tile_base = SPLIT ? (int)blockIdx.z * a.tiles_per_group : 0;
+    const int ntiles = SPLIT ? min(a.tiles_per_group, ((a.P + 15) >> 4) - tile_base) : (a.P + 15) >> 4;
     const int nbatch = (ntiles + W16_BATCH_TILES - 1) / W16_BATCH_TILES;
     const int stride = gridDim.x;
     const int ncand = (a.B - (int)blockIdx.x + stride - 1) / stride;
+    float* pooled = SPLIT ? a.pooled + (size_t)blockIdx.z * a.B * C3 : a.pooled;
 
     // Produce cursor: the (candidate, batch, half) this wave produces next; every wave's cursor moves to the next
     // candidate in the same batch.  The points are loaded one step ahead.  The layer-1 table of a candidate is
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
     bool ptile = first_tile < ntiles;
     TilePoints px;
     if (wave == 0) fold_w1_frags(a, pb, s_w1base, s_w1f, lane);
-    if (ptile) load_tile_points(a, pb, first_tile, c, q, px);
+    if (ptile) load_tile_points(a, pb, tile_base + first_tile, c, q, px);
     __syncthreads();
     auto produce_step = [&](char* batch_base) {
         if (ptile) produce_tiles(px, s_w1f + ptab * W1F_BYTES, ones, s_w2, s_b2, batch_base + first_tile * W16_TILE_BYTES, lane);
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
         }
         const int tile0 = pbt * W16_BATCH_TILES + first_tile;
         ptile = pb < a.B && tile0 < ntiles;
-        if (ptile) load_tile_points(a, pb, tile0, c, q, px);
+        if (ptile) load_tile_points(a, pb, tile_base + tile0, c, q, px);
     };
     produce_step(s_a);
     __syncthreads();
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(WS_THREADS) void conv_stack_bf16_kernel(ConvStackAr
             float m = __builtin_fmaxf(rm[nt], __shfl_xor(rm[nt], 16));
             m = __builtin_fmaxf(m, __shfl_xor(m, 32)) + s_b3[ch];
             if (a.relu_out) m = __builtin_fmaxf(m, 0.f);
-            if (q == 0) a.pooled[(size_t)b * C3 + ch] = m;
+            if (q == 0) pooled[(size_t)b * C3 + ch] = m;
         }
     }
 #ifdef PNGPD_STAMPS
@@ -632,9 +639,16 @@ hipError_t launch_conv_stack_bf16(const ConvStackArgs& a, hipStream_t s) {
         hipError_t er = set_max_lds_once((const void*)kern, WS_LDS_BYTES);
         if (er != hipSuccess) return er;
         const int per_piece = n_cu / pieces > 0 ? n_cu / pieces : 1;
-        hipLaunchKernelGGL(kern, dim3(a.B < per_piece ? a.B : per_piece, pieces), dim3(WS_THREADS), WS_LDS_BYTES, s, a);
+        hipLaunchKernelGGL(kern, dim3(a.B < per_piece ? a.B : per_piece, pieces, a.point_groups), dim3(WS_THREADS),
+                           WS_LDS_BYTES, s, a);
         return hipGetLastError();
     };
+    if (a.point_groups > 1) {
+        // the caller sized the groups with conv_stack_point_groups(): only batches that run the 4-piece cut
+        if (a.B * 4 > n_cu || a.tiles_per_group < 1 || (a.point_groups - 1) * a.tiles_per_group >= ((a.P + 15) >> 4))
+            return hipErrorInvalidValue;
+        return launch(conv_stack_bf16_kernel<2, true>, 4);
+    }
     if (a.B * 4 <= n_cu) return launch(conv_stack_bf16_kernel<2>, 4);
     if (a.B * 2 <= n_cu) return launch(conv_stack_bf16_kernel<4>, 2);
     return launch(conv_stack_bf16_kernel<8>, 1);

@@ -210,9 +210,12 @@ __device__ __forceinline__ void produce_tile_x3(float px, const char* s_w1f, uns
 // too small to give every CU a workgroup runs NT = 2 with grid.y = 4, or NT = 1 with grid.y = 8 (a single candidate,
 // the reference's own call shape).  The arithmetic of a channel does not depend on the cut, so a candidate's result
 // does not depend on the batch it is scored in.
-template <int NT>
+// SPLIT (small batches only): grid.z also cuts the points of a candidate into groups of a.tiles_per_group tiles, each
+// group writing its maxima to pooled + z * B * 1024 (conv_stack.hip, conv_stack_bf16_kernel).
+template <int NT, bool SPLIT = false>
 __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs a) {
     static_assert(NT == 4 || NT == 2 || NT == 1, "channel tiles per wave");
+    static_assert(!SPLIT || NT == 1, "only the single-candidate shape is cut over points");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: scalar branches and addresses
@@ -251,8 +254,10 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
     lds_dma_wait();
     __syncthreads();
 
-    const int ntiles = (a.P + 15) >> 4;
+    const int tile_base = SPLIT ? (int)blockIdx.z * a.tiles_per_group : 0;
+    const int ntiles = SPLIT ? min(a.tiles_per_group, ((a.P + 15) >> 4) - tile_base) : (a.P + 15) >> 4;
     const int nbatch = (ntiles + X3_BATCH_TILES - 1) / X3_BATCH_TILES;      // every batch runs all 8 tiles
+    float* pooled = SPLIT ? a.pooled + (size_t)blockIdx.z * a.B * C3 : a.pooled;
     const int stride = gridDim.x;
     const int ncand = (a.B - (int)blockIdx.x + stride - 1) / stride;
 
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
     int lb = blockIdx.x, lbt = 0, ltab = 0;
     float px = 0.f;
     auto fetch_point = [&]() {
-        if (lb < a.B) px = load_tile_point(a, lb, lbt * X3_BATCH_TILES + wave, c, q);
+        if (lb < a.B) px = load_tile_point(a, lb, tile_base + lbt * X3_BATCH_TILES + wave, c, q);
     };
     auto advance = [&]() {
         if (++lbt == nbatch) {
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv_stack_x3_kernel(ConvStackArgs
             float m = __builtin_fmaxf(rm[nt], __shfl_xor(rm[nt], 16));
             m = __builtin_fmaxf(m, __shfl_xor(m, 32)) + s_b3[ch];
             if (a.relu_out) m = __builtin_fmaxf(m, 0.f);
-            if (q == 0) a.pooled[(size_t)b * C3 + ch] = m;
+            if (q == 0) pooled[(size_t)b * C3 + ch] = m;
         }
     }
 }
@@ -405,12 +410,44 @@ hipError_t launch_conv_stack_x3(const ConvStackArgs& a, hipStream_t s) {
         hipError_t er = set_max_lds_once((const void*)kern, X3_LDS_BYTES);
         if (er != hipSuccess) return er;
         const int per_piece = n_cu / pieces > 0 ? n_cu / pieces : 1;
-        hipLaunchKernelGGL(kern, dim3(a.B < per_piece ? a.B : per_piece, pieces), dim3(X3_THREADS), X3_LDS_BYTES, s, a);
+        hipLaunchKernelGGL(kern, dim3(a.B < per_piece ? a.B : per_piece, pieces, a.point_groups), dim3(X3_THREADS),
+                           X3_LDS_BYTES, s, a);
         return hipGetLastError();
     };
+    if (a.point_groups > 1) {
+        // the caller sized the groups with conv_stack_point_groups(): only batches that run the 8-piece cut
+        if (a.B * 8 > n_cu || a.tiles_per_group < 1 || (a.point_groups - 1) * a.tiles_per_group >= ((a.P + 15) >> 4))
+            return hipErrorInvalidValue;
+        return launch(conv_stack_x3_kernel<1, true>, 8);
+    }
     if (a.B * 8 <= n_cu) return launch(conv_stack_x3_kernel<1>, 8);
     if (a.B * 4 <= n_cu) return launch(conv_stack_x3_kernel<2>, 4);
     return launch(conv_stack_x3_kernel<4>, 2);
+}
+
+hipError_t conv_stack_point_groups(int precision, int B, int P, int* groups, int* tiles_per_group) {
+    *groups = 1;
+    *tiles_per_group = 0;
+    if (B < 1 || P < 1) return hipErrorInvalidValue;
+    if (B > CONV_SPLIT_MAX_B || (precision != PNGPD_BF16 && precision != PNGPD_BF16X3)) return hipSuccess;
+    int n_cu = 0;
+    hipError_t e = device_cu_count(&n_cu);
+    if (e != hipSuccess) return e;
+    // channel pieces and tiles per batch of the kernels that run such a batch (launch_conv_stack_bf16 / _x3)
+    const int pieces = precision == PNGPD_BF16 ? 4 : 8;
+    const int batch_tiles = precision == PNGPD_BF16 ? 16 : X3_BATCH_TILES;
+    if (B * pieces > n_cu) return hipSuccess;
+    int room = n_cu / (B * pieces);                    // groups for which every workgroup still has a CU of its own
+    if (room > CONV_SPLIT_MAX_GROUPS) room = CONV_SPLIT_MAX_GROUPS;
+    if (room < 2) return hipSuccess;
+    const int ntiles = (P + 15) >> 4;
+    const int nbatch = (ntiles + batch_tiles - 1) / batch_tiles;
+    const int tpg = (nbatch + room - 1) / room * batch_tiles;      // whole batches per group
+    const int g = (ntiles + tpg - 1) / tpg;
+    if (g < 2) return hipSuccess;
+    *groups = g;
+    *tiles_per_group = tpg;
+    return hipSuccess;
 }
 
 }  // namespace pngpd

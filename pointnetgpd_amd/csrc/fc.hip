@@ -6,6 +6,8 @@
 //   score:   softmax of the log-probabilities and first-index arg-max (main_test.py:80-81).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace pngpd {
@@ -476,28 +478,52 @@ __global__ __launch_bounds__(256) void fc_bf16x3_direct_kernel(const float* __re
 // single accumulator, same k order and product order as the two kernels above: bit-identical results.
 // What is left is the chain itself: K / 16 x 3 dependent MFMAs.
 constexpr int X3R_BLOCK = 4;                          // k-steps per register block
+#ifndef PNGPD_X3R_RING
+#define PNGPD_X3R_RING 3
+#endif
+constexpr int X3R_RING = PNGPD_X3R_RING;              // register blocks in flight + the one being multiplied
+constexpr int X3R_MERGE_MAX_M = 8;                    // rows of the MERGE variant (its LDS image is M x (K + 8) floats)
+constexpr int X3R_MERGE_PAD = 8;                      // floats between rows in LDS: rows start 8 banks apart
+constexpr int X3R_MERGE_GROUPS = CONV_SPLIT_MAX_GROUPS;
 
+// MERGE: X is [groups][M][K] partial maxima of the conv stack of a small batch that was cut over points
+// (conv_stack_point_groups): the rows this layer multiplies are their element-wise maximum over the groups, taken here
+// by all 64 lanes with coalesced loads into LDS (K <= 1024, M <= 8), while the first weight blocks are already in flight;
+// workgroup 0 also stores the merged rows to `merged` when the caller wants them (the global feature).
+template <bool MERGE>
 __global__ __launch_bounds__(64) void fc_bf16x3_rows32_kernel(const float* __restrict__ X, const char* __restrict__ Wp,
                                                               const float* __restrict__ bias, float* __restrict__ Y,
-                                                              int M, int N, int K, int relu) {
+                                                              int M, int N, int K, int relu, int groups,
+                                                              float* __restrict__ merged) {
+    __shared__ __attribute__((aligned(16))) float s_x[MERGE ? X3R_MERGE_MAX_M * (1024 + X3R_MERGE_PAD) : 4];
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int ksteps = K / 16, nblk = ksteps / X3R_BLOCK;
     const int row = r < M ? r : M - 1;                 // rows beyond M repeat the last one; their results are not stored
-    const float* a_src = X + (size_t)row * K + 8 * h;
+    const float* a_src = MERGE ? s_x + row * (K + X3R_MERGE_PAD) + 8 * h : X + (size_t)row * K + 8 * h;
     const char* b_src = Wp + ((size_t)blockIdx.x * ksteps * 2) * 1024 + lane * 16;
     struct Block {
         float4 a[X3R_BLOCK][2];
         bf16x8_t b[X3R_BLOCK][2];
     };
-    auto load = [&](int kb, Block& blk) {
+    auto load_b = [&](int kb, Block& blk) {
+#pragma unroll
+        for (int u = 0; u < X3R_BLOCK; ++u) {
+            const int ks = kb * X3R_BLOCK + u;
+            blk.b[u][0] = *(const bf16x8_t*)(b_src + ((size_t)ks * 2) * 1024);
+            blk.b[u][1] = *(const bf16x8_t*)(b_src + ((size_t)ks * 2 + 1) * 1024);
+        }
+    };
+    auto load_a = [&](int kb, Block& blk) {
 #pragma unroll
         for (int u = 0; u < X3R_BLOCK; ++u) {
             const int ks = kb * X3R_BLOCK + u;
             blk.a[u][0] = *(const float4*)(a_src + 16 * ks);
             blk.a[u][1] = *(const float4*)(a_src + 16 * ks + 4);
-            blk.b[u][0] = *(const bf16x8_t*)(b_src + ((size_t)ks * 2) * 1024);
-            blk.b[u][1] = *(const bf16x8_t*)(b_src + ((size_t)ks * 2 + 1) * 1024);
         }
+    };
+    auto load = [&](int kb, Block& blk) {
+        load_a(kb, blk);
+        load_b(kb, blk);
     };
     f32x16 acc = f32x16{0};
     auto compute = [&](const Block& blk) {
@@ -516,15 +542,61 @@ __global__ __launch_bounds__(64) void fc_bf16x3_rows32_kernel(const float* __res
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blk.b[u][0], acc, 0, 0, 0);
         }
     };
-    Block ring[3];
-    load(0, ring[0]);
-    if (nblk > 1) load(1, ring[1]);
-    for (int kb0 = 0; kb0 < nblk; kb0 += 3) {           // slots are compile-time constants
+    // The weight blocks are requested X3R_RING - 1 blocks ahead.  A ring of six (20 k-steps, ~2,000 cycles of MFMAs ahead)
+    // measured the same as three at one row (9.0 us for K = 1024): what bounds the layer there is the chain of
+    // K / 16 x 3 dependent MFMAs behind two memory round trips, not the depth of the ring.
+    Block ring[X3R_RING];
+    if (MERGE) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < X3R_RING - 1; ++u)
+            if (u < nblk) load_b(u, ring[u]);
+        const size_t gstride = (size_t)M * K;
+        const int total = M * K;                                   // K is a multiple of 64: a multiple of 256
+        // J float4 per lane and pass, every group's load of all J in flight together (32 loads; a group index beyond
+        // `groups` repeats group 0: a maximum does not change when an operand is repeated)
+        auto merge = [&](auto gc, auto jc) {
+            constexpr int G = decltype(gc)::value, J = decltype(jc)::value;
+            for (int i0 = lane * 4; i0 < total; i0 += J * 256) {
+                float4 v[J][G];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const int i = i0 + j * 256 < total ? i0 + j * 256 : i0;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) v[j][g] = *(const float4*)(X + (g < groups ? g : 0) * gstride + i);
+                }
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const int i = i0 + j * 256;
+                    if (i >= total) break;
+                    float4 m = v[j][0];
+#pragma unroll
+                    for (int g = 1; g < G; ++g) {
+                        m.x = __builtin_fmaxf(m.x, v[j][g].x); m.y = __builtin_fmaxf(m.y, v[j][g].y);
+                        m.z = __builtin_fmaxf(m.z, v[j][g].z); m.w = __builtin_fmaxf(m.w, v[j][g].w);
+                    }
+                    const int mr = i / K, mk = i - mr * K;
+                    *(float4*)(s_x + mr * (K + X3R_MERGE_PAD) + mk) = m;
+                    if (merged != nullptr && blockIdx.x == 0) *(float4*)(merged + i) = m;
+                }
+            }
+        };
+        if (groups <= 4) merge(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
+        else merge(std::integral_constant<int, X3R_MERGE_GROUPS>{}, std::integral_constant<int, 4>{});
+        __syncthreads();                                           // one wave: orders its own LDS writes and reads
+#pragma unroll
+        for (int u = 0; u < X3R_RING - 1; ++u)
+            if (u < nblk) load_a(u, ring[u]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < X3R_RING - 1; ++u)
+            if (u < nblk) load(u, ring[u]);
+    }
+    for (int kb0 = 0; kb0 < nblk; kb0 += X3R_RING) {    // slots are compile-time constants
+#pragma unroll
+        for (int u = 0; u < X3R_RING; ++u) {
             const int kb = kb0 + u;
             if (kb >= nblk) break;
-            if (kb + 2 < nblk) load(kb + 2, ring[(u + 2) % 3]);
+            if (kb + X3R_RING - 1 < nblk) load(kb + X3R_RING - 1, ring[(u + X3R_RING - 1) % X3R_RING]);
             compute(ring[u]);
         }
     }
@@ -542,11 +614,16 @@ __global__ __launch_bounds__(64) void fc_bf16x3_rows32_kernel(const float* __res
 }
 
 hipError_t launch_fc_bf16x3(const float* X, const void* Wp, const float* b, float* Y, int M, int N, int K, int relu,
-                            hipStream_t s) {
-    if (!X || !Wp || !b || !Y || M < 1 || N % X3_BN != 0 || K % X3_BK != 0) return hipErrorInvalidValue;
+                            hipStream_t s, int groups, float* merged) {
+    if (!X || !Wp || !b || !Y || M < 1 || N % X3_BN != 0 || K % X3_BK != 0 || groups < 1) return hipErrorInvalidValue;
     const long long wg64 = (long long)(N / X3_BN) * ((M + 63) / 64);
-    if (M <= 32 && K % (16 * X3R_BLOCK) == 0) {
-        hipLaunchKernelGGL(fc_bf16x3_rows32_kernel, dim3(N / 32), dim3(64), 0, s, X, (const char*)Wp, b, Y, M, N, K, relu);
+    if (groups > 1) {
+        if (M > X3R_MERGE_MAX_M || K > 1024 || K % 64 != 0 || groups > X3R_MERGE_GROUPS) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(fc_bf16x3_rows32_kernel<true>, dim3(N / 32), dim3(64), 0, s, X, (const char*)Wp, b, Y, M, N, K,
+                           relu, groups, merged);
+    } else if (M <= 32 && K % (16 * X3R_BLOCK) == 0) {
+        hipLaunchKernelGGL(fc_bf16x3_rows32_kernel<false>, dim3(N / 32), dim3(64), 0, s, X, (const char*)Wp, b, Y, M, N, K,
+                           relu, 1, (float*)nullptr);
     } else if (wg64 >= 1024) {      // at least ~4 workgroups per CU with 64-row tiles
         dim3 grid(N / X3_BN, (M + 63) / 64);
         hipLaunchKernelGGL(fc_bf16x3_kernel<64>, grid, dim3(256), 0, s, X, (const char*)Wp, b, Y, M, N, K, relu);

@@ -48,7 +48,19 @@ struct ConvStackArgs {
     int relu_out;          // 1: ReLU after the max (STN), 0: none (trunk)
     const void* w2lo = nullptr;   // bf16x3 only: second bf16 piece of the conv2 / conv3 weights, same fragment order
     const void* w3lo = nullptr;
+    // Small batches (conv_stack_point_groups() > 1): the points of a candidate are cut into point_groups groups of
+    // tiles_per_group tiles of 16, and `pooled` is [point_groups][B][1024] partial maxima (bias and ReLU applied to
+    // each), whose maximum over the groups is the pooled row.
+    int point_groups = 1;
+    int tiles_per_group = 0;
 };
+
+// Into how many groups of points launch_conv_stack_bf16 / _x3 can cut a candidate of this batch (1: not at all), and
+// the tiles of 16 points per group.  Only batches of at most CONV_SPLIT_MAX_B candidates are cut, into at most
+// CONV_SPLIT_MAX_GROUPS groups, and only while all workgroups of the launch fit the chip at once.
+constexpr int CONV_SPLIT_MAX_B = 8;
+constexpr int CONV_SPLIT_MAX_GROUPS = 8;
+hipError_t conv_stack_point_groups(int precision, int B, int P, int* groups, int* tiles_per_group);
 
 hipError_t launch_conv_stack_bf16(const ConvStackArgs& a, hipStream_t s);
 hipError_t launch_conv_stack_f32(const ConvStackArgs& a, hipStream_t s);
@@ -74,8 +86,10 @@ hipError_t launch_fc_f32(const float* X, const float* W, const float* b, float* 
 
 // Same layer with split-bf16 operands (3 bf16 MFMAs per product term); Wp from pack_fc_split.
 // N % 128 == 0, K % 32 == 0.
+// groups > 1: X is [groups][M][K] and the layer's input rows are the element-wise maximum over the groups (the
+// partial maxima of a conv stack cut over points, M <= 8, K <= 1024); `merged` (optional) receives those rows.
 hipError_t launch_fc_bf16x3(const float* X, const void* Wp, const float* b, float* Y, int M, int N, int K, int relu,
-                            hipStream_t s);
+                            hipStream_t s, int groups = 1, float* merged = nullptr);
 
 enum { FC_TAIL_PLAIN = 0, FC_TAIL_ADD_IDENTITY = 1, FC_TAIL_LOG_SOFTMAX = 2 };
 constexpr int FC_TAIL_K = 256;   // input width of the last layer of both FC chains (model/pointnet.py:24, :182)

@@ -325,3 +325,32 @@ def test_main_test_command_line(tmp_path, capsys):
     assert list(votes) == singles and votes.shape == (10,)
     counts = np.bincount(votes, minlength=k)
     assert counts[winner] == counts.max() and winner == int(np.argmax(counts))
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("P", [750, 500, 241, 1000, 2500, 16])
+def test_small_batches_cut_over_points_are_bitwise_equal_to_rows_of_a_large_batch(precision, P):
+    """A batch of at most 8 candidates (main_test.py:73-83 scores one per call) runs the conv stacks cut over channel
+    pieces AND point groups, with the FC layer behind each stack merging the groups' partial maxima.  A maximum does
+    not depend on how its operands are grouped, so every output - log-probabilities, transform and the merged global
+    feature - must equal, bit for bit, the same candidates' rows of a batch of 64 (which is not cut over points)."""
+    seed = 23
+    m = hip_model(P, 2, seed, 0.02, precision)
+    x = torch.from_numpy(synth.candidate_points(seed, 64, P, "gripper")).cuda()
+    logp, trans, feat = m._infer(x, 0, True, True)
+    for B in (1, 2, 3, 8):
+        rows = torch.arange(5, 5 + B, device="cuda")
+        sub_logp, sub_trans, sub_feat = m._infer(x[rows].contiguous(), 0, True, True)
+        assert torch.equal(sub_logp, logp[rows]), (precision, P, B)
+        assert torch.equal(sub_trans, trans[rows]), (precision, P, B)
+        assert torch.equal(sub_feat, feat[rows]), (precision, P, B)
+    # modules without a head: the trunk's stack has no FC layer behind it and is not cut over points; the STN's is
+    sd = {k[len("feat."):]: v for k, v in synth.torch_state_dict(seed, 2, 0.02).items() if k.startswith("feat.")}
+    f = PointNetfeat(P, 3)
+    f.load_state_dict(sd)
+    f = f.cuda().eval()
+    f.precision = precision
+    g64, t64 = f(x)
+    g1, t1 = f(x[7:8].contiguous())
+    assert torch.equal(g1, g64[7:8]) and torch.equal(t1, t64[7:8])
+    assert torch.equal(g64, feat) and torch.equal(t64, trans)
