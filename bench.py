@@ -299,27 +299,33 @@ def train_workload(args, dev, rank, n_gpus, dist):
 
 def _train_roofline(conv3_tf, conv3_ms, conv3_flop, B, P):
     """Roofline entry of the training step's dominant kernel, the fused conv3 product / max / arg-max.  Its default
-    form computes float32-grade products on the bfloat16 matrix pipe: every operand is split into three bfloat16
-    pieces and six piece products are accumulated, so a launch executes 6 x the algorithmic flops on
-    v_mfma_f32_32x32x16_bf16.  `achieved` is algorithmic flops over time, as for every other line; `peak` is what the
-    pipe can deliver of such products, the dense bfloat16 peak / 6.  PNGPD_TRAIN_CONV3=f32 selects the float32
-    matrix instruction instead (peak 157.3)."""
-    if os.environ.get("PNGPD_TRAIN_CONV3", "").startswith("f"):
-        peak, kernel = PEAK_TFLOPS["fp32"], "conv3_pool_train_kernel (v_mfma_f32_32x32x2_f32)"
-    else:
-        peak = round(PEAK_TFLOPS["bf16"] / 6.0, 1)
+    form computes float32-grade products on the 16-bit matrix pipe: every operand is split into two float16 pieces
+    (power-of-two scaled into float16's range) and three piece products are accumulated, so a launch executes 3 x the
+    algorithmic flops on v_mfma_f32_32x32x16_f16.  `achieved` is algorithmic flops over time, as for every other line;
+    `peak` is what the pipe can deliver of such products, the dense 16-bit peak / 3.  PNGPD_TRAIN_CONV3=x6 selects six
+    products of bfloat16 pieces (peak / 6), =f32 the float32 matrix instruction (peak 157.3)."""
+    mode = os.environ.get("PNGPD_TRAIN_CONV3", "")
+    if mode.startswith("f"):
+        peak, kernel, mult = PEAK_TFLOPS["fp32"], "conv3_pool_train_kernel (v_mfma_f32_32x32x2_f32)", None
+    elif mode.startswith("x"):
+        peak, mult = round(PEAK_TFLOPS["bf16"] / 6.0, 1), 6.0
         kernel = ("conv3_pool_train_x6_kernel (float32-grade products as 6 bf16 piece products on "
                   "v_mfma_f32_32x32x16_bf16; peak = dense bf16 peak / 6)")
+    else:
+        peak, mult = round(PEAK_TFLOPS["bf16"] / 3.0, 1), 3.0
+        kernel = ("conv3_pool_train_h3_kernel (float32-grade products as 3 float16 piece products on "
+                  "v_mfma_f32_32x32x16_f16; peak = dense 16-bit peak / 3)")
     # HBM bytes per launch from the committed PMC passes, when they ran this kernel at this size
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r2_train_conv3_traffic.json")
-    if os.path.exists(tpath) and peak != PEAK_TFLOPS["fp32"]:
+    tname = "r3_train_conv3_h3_traffic.json" if mult == 3.0 else "r2_train_conv3_traffic.json"
+    tpath = os.path.join(ROOT, "profiles", tname)
+    if os.path.exists(tpath) and mult is not None:
         t = json.load(open(tpath))
         if t["config"] == {"B": B, "P": P}:
             traffic = t["hbm_bytes_per_launch"]
     return {"bound": "mfma", "kernel": kernel, "achieved": round(conv3_tf, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(conv3_tf / peak, 4), "traffic": traffic, "kernel_ms": round(conv3_ms, 4),
-            "flop_per_launch": conv3_flop, "executed_bf16_tflops": round(6.0 * conv3_tf, 1) if peak != PEAK_TFLOPS["fp32"] else None}
+            "flop_per_launch": conv3_flop, "executed_16bit_tflops": round(mult * conv3_tf, 1) if mult else None}
 
 
 def voxel_workload(args, dev, rank, n_gpus, dist):

@@ -204,7 +204,9 @@ struct Conv3Ws {
     double* abar_d;    // [128] column mean of the input rows
     double* cov;       // [128,128] covariance of the input rows
     float* w3p;        // [1024*128] weights scaled by gamma*rstd, packed for the product/max kernel
-    unsigned short* w3s;   // [3*1024*128] the same weights as three bfloat16 pieces in 32x32x16 fragment order
+    unsigned short* w3s;   // [3*1024*128] the same weights as three bfloat16 pieces in 32x32x16 fragment order, or (the
+                           // first two thirds) as two float16 pieces of the rows scaled by 1 / wsc
+    float* wsc = nullptr;  // [1024] per channel: the power of two that undoes the scaling of its float16 row
     float* sh;         // [1024] shift added after the max
     float* gmask;      // [B,1024] pooled gradient after the ReLU mask
     float* G;          // [128,128] W^T diag(q) W

@@ -67,6 +67,7 @@ struct TrainWs {
             s->c3.w3p = a.take<float>((size_t)C3 * C2);
             s->c3.w3s = a.take<unsigned short>((size_t)3 * C3 * C2);
             s->c3.sh = a.take<float>(C3);
+            s->c3.wsc = a.take<float>(C3);
             s->c3.gmask = a.take<float>((size_t)B * C3);
             s->c3.G = a.take<float>((size_t)C2 * C2);
             s->c3.ub = a.take<float>(C2);

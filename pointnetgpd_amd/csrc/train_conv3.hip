@@ -400,6 +400,23 @@ __device__ __forceinline__ int w3s_index(int c, int k) {
     return (((nt * 8 + ks) * 3) * 64 + r + 32 * hh) * 8 + j;
 }
 
+// Index of piece 0 (hi) of W3[c][k] in the split-float16 image: [nt 32][ks 8][piece 2][lane 64][8], the B fragments of
+// v_mfma_f32_32x32x16_f16 (same lane map as the bfloat16 image).  The two pieces are 512 values apart.
+__device__ __forceinline__ int w3h_index(int c, int k) {
+    const int nt = c >> 5, r = c & 31, ks = k >> 4, hh = (k >> 3) & 1, j = k & 7;
+    return (((nt * 8 + ks) * 2) * 64 + r + 32 * hh) * 8 + j;
+}
+
+// The power of two that moves m (>= 0) into [2^13, 2^14); 1 for m = 0 or not finite.  Clamped so that the factor and
+// its reciprocal stay normal floats.
+__device__ __forceinline__ float pow2_scale_to_2p13(float m) {
+    const int e = (int)((__builtin_bit_cast(unsigned int, m) >> 23) & 0xffu);      // biased exponent of m
+    if (e == 0xff || m == 0.f) return 1.0f;
+    int sx = 13 - (e - 127);
+    sx = sx > 120 ? 120 : (sx < -120 ? -120 : sx);
+    return __builtin_bit_cast(float, (unsigned int)(127 + sx) << 23);
+}
+
 // one block of 128 threads per channel
 __global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restrict__ W3, const float* __restrict__ b3,
                                                           const float* __restrict__ gamma,
@@ -410,9 +427,10 @@ __global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restric
                                                           float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float* __restrict__ w3p,
                                                           unsigned short* __restrict__ w3s,
-                                                          float* __restrict__ sh) {
+                                                          float* __restrict__ sh, float* __restrict__ wsc) {
     __shared__ double s_w[C2], s_q[C2], s_m[C2];
     __shared__ float s_sc;
+    __shared__ float s_max[2];
     const int c = blockIdx.x, i = threadIdx.x;
     const float wf = W3[(size_t)c * C2 + i];
     s_w[i] = (double)wf;
@@ -445,7 +463,25 @@ __global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restric
     __syncthreads();
     const float wv = wf * s_sc;
     w3p[w3p_index(c, i)] = wv;
-    if (w3s != nullptr) {
+    if (w3s != nullptr && wsc != nullptr) {
+        // The same weight as TWO float16 pieces (conv3_pool_train_h3_kernel): the channel's row is first scaled by a
+        // power of two that puts its largest entry in [2^13, 2^14) - float16 has 11 significand bits but only 5
+        // exponent bits - so that hi + lo carries 22 bits of every entry within 2^17 of the largest; wsc[c] undoes it.
+        float m = fabsf(wv);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if ((i & 63) == 0) s_max[i >> 6] = m;
+        __syncthreads();
+        m = fmaxf(s_max[0], s_max[1]);
+        const float up = pow2_scale_to_2p13(m);
+        if (i == 0) wsc[c] = 1.0f / up;                       // a power of two: exact
+        const float ws = wv * up;
+        const _Float16 hi = (_Float16)ws;
+        const _Float16 lo = (_Float16)(ws - (float)hi);
+        const int base = w3h_index(c, i);
+        w3s[base] = __builtin_bit_cast(unsigned short, hi);
+        w3s[base + 512] = __builtin_bit_cast(unsigned short, lo);
+    } else if (w3s != nullptr) {
         // the same weight as three bfloat16 pieces (wv = hi + mid + lo to 2^-27), in 32x32x16 fragment order
         const __bf16 hi = (__bf16)wv;
         const float r1 = wv - (float)hi;
@@ -764,6 +800,180 @@ __global__ __launch_bounds__(TC_THREADS, 2) void conv3_pool_train_x6_kernel(cons
     }
 }
 
+// The same product with every operand as TWO float16 pieces and THREE piece products:
+//     x w ~ xl wh + xh wl + xh wh
+// float16 carries 11 significand bits, so hi + lo holds 22 bits of an operand (the bfloat16 split above needs three
+// pieces for 24) and what is dropped - xl wl and the two representation remainders - is below 3 * 2^-22 of the product:
+// the size of the float32 accumulation's own rounding over 128 terms.  Half the MFMAs of the six-product kernel.
+// float16 has only 5 exponent bits, so both operands are scaled by powers of two first (exact): a weight row by the
+// factor that k_conv3_stats_pack chose for its channel (largest entry in [2^13, 2^14)), the 64 points a wave holds in a
+// pass by the factor that does the same for the largest activation among them.  Entries within 2^17 of the largest keep
+// all 22 bits; smaller ones lose low bits whose weight is below 2^-39 of the largest entry.  A product of two scaled
+// operands is below 2^28 and a sum of 128 below 2^35.  The maxima of a pass are compared in the scaled domain (one
+// positive factor per wave, pass and channel) and descaled before they meet the maxima of other passes and waves.
+// Same grid and epilogue as the kernels above; a weight chunk is a whole 32-channel tile (16 KiB).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+constexpr int TH_CHUNK_BYTES = 16384;    // a 32-channel tile: 8 k-steps x 2 pieces x 1 KiB
+
+__device__ __forceinline__ void th_dma_chunk(const char* src, char* dst, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;
+        __builtin_amdgcn_global_load_lds((const void*)(src + piece * 1024 + lane * 16), (lds_void*)(dst + piece * 1024),
+                                         16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(TC_THREADS, 2) void conv3_pool_train_h3_kernel(const float* __restrict__ h,
+                                                                            const unsigned short* __restrict__ w3h,
+                                                                            const float* __restrict__ wsc,
+                                                                            const float* __restrict__ sh, int P,
+                                                                            int relu, int ntb,
+                                                                            float* __restrict__ pooled,
+                                                                            int* __restrict__ arg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.x, nt0 = blockIdx.y * ntb;
+    const int nch = 32 * ntb;
+    char* s_w3 = smem;
+    float* s_red = (float*)(smem + 2 * TH_CHUNK_BYTES);      // [4][nch]
+    int* s_arg = (int*)(s_red + TC_WAVES * nch);             // [4][nch]
+    float* s_wsc = (float*)(s_arg + TC_WAVES * nch);         // [nch]
+    const char* g_w3 = (const char*)w3h + (size_t)nt0 * TH_CHUNK_BYTES;
+
+    th_dma_chunk(g_w3, s_w3, wave, lane);
+    for (int c = tid; c < TC_WAVES * nch; c += TC_THREADS) {
+        s_red[c] = -INFINITY;
+        s_arg[c] = 0;
+    }
+    for (int c = tid; c < nch; c += TC_THREADS) s_wsc[c] = wsc[32 * nt0 + c];
+    lds_dma_wait();
+    __syncthreads();
+
+    float* s_red_wave = s_red + wave * nch;
+    int* s_arg_wave = s_arg + wave * nch;
+    const int pts_per_pass = TC_WAVES * 32 * TC_MT;
+    const int npass = (P + pts_per_pass - 1) / pts_per_pass;
+
+    for (int pass = 0; pass < npass; ++pass) {
+        // A operands: piece [mt][ks] of lane (r, hh) holds k = 16ks + 8hh + j of point r of tile mt
+        f16x8 Ah[TC_MT][8], Al[TC_MT][8];
+        const int pt_base = pass * pts_per_pass + wave * TC_MT * 32;
+        float xdescale;
+        {
+            f32x4 v[TC_MT][8][2];
+            float m = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < TC_MT; ++mt) {
+                int pt = pt_base + mt * 32 + r;
+                pt = pt < P ? pt : P - 1;                   // duplicates of the last point cannot change a maximum
+                const float* hp = h + ((size_t)b * P + pt) * C2 + 8 * hh;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    v[mt][ks][0] = *(const f32x4*)(hp + 16 * ks);
+                    v[mt][ks][1] = *(const f32x4*)(hp + 16 * ks + 4);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < TC_MT; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m = __builtin_fmaxf(m, __builtin_fabsf(v[mt][ks][j >> 2][j & 3]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off));
+            const float up = pow2_scale_to_2p13(m);
+            xdescale = 1.0f / up;                          // a power of two: exact
+#pragma unroll
+            for (int mt = 0; mt < TC_MT; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = v[mt][ks][j >> 2][j & 3] * up;
+                        const _Float16 xh = (_Float16)x;
+                        Ah[mt][ks][j] = xh;
+                        Al[mt][ks][j] = (_Float16)(x - (float)xh);
+                    }
+        }
+        const bool last_pass = (pass == npass - 1);
+        for (int nt = 0; nt < ntb; ++nt) {
+            f32x16 acc[TC_MT];
+#pragma unroll
+            for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = f32x16{0};
+            if (!(last_pass && nt == ntb - 1)) {
+                const int nxt = nt + 1 < ntb ? nt + 1 : 0;
+                th_dma_chunk(g_w3 + (size_t)nxt * TH_CHUNK_BYTES, s_w3 + ((nt + 1) & 1) * TH_CHUNK_BYTES, wave, lane);
+            }
+            const char* buf = s_w3 + (nt & 1) * TH_CHUNK_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const f16x8 bh = *(const f16x8*)(buf + ((ks * 2 + 0) * 64 + lane) * 16);
+                const f16x8 bl = *(const f16x8*)(buf + ((ks * 2 + 1) * 64 + lane) * 16);
+                // smallest products first
+#pragma unroll
+                for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[mt][ks], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[mt][ks], bl, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[mt][ks], bh, acc[mt], 0, 0, 0);
+            }
+            lds_dma_wait();             // the chunk issued at the top of this tile landed long ago, behind the MFMAs
+            __syncthreads();
+            // accumulator register i of lane half hh is point (i&3) + 8(i>>2) + 4hh of the tile, channel 32nt + r:
+            // ascending i is ascending point index, so a strict compare keeps the first maximum.  (Hiding this search
+            // under the MFMAs of the next tile - two accumulator sets, the search cut into eight parts between the
+            // k-steps - was measured: 1.635 ms per step either way.)
+            float bv = -INFINITY;
+            int bi = 0;
+#pragma unroll
+            for (int mt = 0; mt < TC_MT; ++mt) {
+                const int base = pt_base + mt * 32 + 4 * hh;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = acc[mt][i];
+                    const int idx = base + (i & 3) + 8 * (i >> 2);
+                    if (v > bv) {
+                        bv = v;
+                        bi = idx;
+                    }
+                }
+            }
+            bi = bi < P ? bi : P - 1;
+            const float ov = __shfl_xor(bv, 32);
+            const int oi = __shfl_xor(bi, 32);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+            bv *= xdescale * s_wsc[32 * nt + r];            // powers of two: the product and the scaling are exact
+            if (hh == 0 && bv > s_red_wave[32 * nt + r]) {   // later passes hold later points: strict compare
+                s_red_wave[32 * nt + r] = bv;
+                s_arg_wave[32 * nt + r] = bi;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < nch; c += TC_THREADS) {
+        float bv = s_red[c];
+        int bi = s_arg[c];
+#pragma unroll
+        for (int w = 1; w < TC_WAVES; ++w) {
+            const float v = s_red[w * nch + c];
+            const int i = s_arg[w * nch + c];
+            if (v > bv || (v == bv && i < bi)) {
+                bv = v;
+                bi = i;
+            }
+        }
+        const int ch = 32 * nt0 + c;
+        bv += sh[ch];
+        pooled[(size_t)b * C3 + ch] = relu ? __builtin_fmaxf(bv, 0.f) : bv;
+        arg[(size_t)b * C3 + ch] = bi;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
@@ -1027,8 +1237,14 @@ hipError_t t_conv3_fwd(float* h2, const float* W3, const float* b3, const float*
     // 32x32 blocks of a partial that its kernel wrote (bit 4 i + j)
     hipLaunchKernelGGL(k_gram_finalize, dim3(C2 * C2 / 16), dim3(256), 0, s, (const double*)gram_part, chunks,
                        (const double*)w.abar_d, M, w.cov, gram_f64 ? 0xCCFFu : 0xAC6Fu);
+    // PNGPD_TRAIN_CONV3 selects the instruction of the product/max kernel: f32 (v_mfma_f32_32x32x2_f32), x6 (six products of
+    // bfloat16 pieces), default h3 (three products of float16 pieces); read at every call, like PNGPD_TRAIN_GRAM above
+    const char* conv3_env = getenv("PNGPD_TRAIN_CONV3");
+    const bool use_f32 = (conv3_env && conv3_env[0] == 'f') || w.w3s == nullptr;
+    const bool use_x6 = !use_f32 && ((conv3_env && conv3_env[0] == 'x') || w.wsc == nullptr);
     hipLaunchKernelGGL(k_conv3_stats_pack, dim3(C3), dim3(128), 0, s, W3, b3, gamma, beta, (const double*)w.cov,
-                       (const double*)w.abar_d, M, momentum, mean, rstd, running_mean, running_var, w.w3p, w.w3s, w.sh);
+                       (const double*)w.abar_d, M, momentum, mean, rstd, running_mean, running_var, w.w3p, w.w3s, w.sh,
+                       use_x6 ? (float*)nullptr : w.wsc);
     // enough workgroups for two per CU: split the channels of a candidate when the batch is small
     // (B = 256 on 256 CUs: 444 / 408 / 422 / 458 us with 1 / 2 / 4 / 8 pieces)
     int dev = 0, n_cu = 0;
@@ -1039,17 +1255,22 @@ hipError_t t_conv3_fwd(float* h2, const float* W3, const float* b3, const float*
     int cs = 1;
     while (cs < 8 && B * cs < 2 * n_cu) cs *= 2;
     const int ntb = 32 / cs;
-    // PNGPD_TRAIN_CONV3=f32 keeps the product on the float32 matrix instruction (the split-bfloat16 form is the default);
-    // read at every call, like PNGPD_TRAIN_GRAM above
-    const char* conv3_env = getenv("PNGPD_TRAIN_CONV3");
-    const bool use_f32 = conv3_env && conv3_env[0] == 'f';
-    if (use_f32 || w.w3s == nullptr) {
+    if (use_f32) {
         const size_t lds = 2 * TC_CHUNK_BYTES + (size_t)TC_WAVES * 32 * ntb * 8;
         e = hipFuncSetAttribute((const void*)conv3_pool_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         if (w.ev_begin != nullptr && (e = hipEventRecord(w.ev_begin, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(conv3_pool_train_kernel, dim3(B, cs), dim3(TC_THREADS), lds, s, h2, (const float*)w.w3p,
                            (const float*)w.sh, P, relu_out, ntb, pooled, arg);
+    } else if (!use_x6) {
+        const size_t lds = 2 * TH_CHUNK_BYTES + (size_t)TC_WAVES * 32 * ntb * 8 + (size_t)32 * ntb * 4;
+        e = hipFuncSetAttribute((const void*)conv3_pool_train_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        if (e != hipSuccess) return e;
+        if (w.ev_begin != nullptr && (e = hipEventRecord(w.ev_begin, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(conv3_pool_train_h3_kernel, dim3(B, cs), dim3(TC_THREADS), lds, s, h2,
+                           (const unsigned short*)w.w3s, (const float*)w.wsc, (const float*)w.sh, P, relu_out, ntb, pooled,
+                           arg);
     } else {
         const size_t lds = 2 * TX_CHUNK_BYTES + (size_t)TC_WAVES * 32 * ntb * 8;
         e = hipFuncSetAttribute((const void*)conv3_pool_train_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

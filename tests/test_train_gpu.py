@@ -520,3 +520,43 @@ def test_gram_on_bf16_pieces_agrees_with_the_float64_gram(monkeypatch):
         print(f"{name}: max difference relative to the largest entry {rel:.2e}")
         assert rel <= 1e-6, (name, rel)
     assert (out["x6"][0] - out["f64"][0]).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("act_scale,w_scale", [(1.0, 1.0), (3.0e3, 2.0e-4), (1.0e-3, 5.0e2), (6.0e4, 1.0)])
+def test_conv3_on_float16_pieces_agrees_with_the_other_products(monkeypatch, act_scale, w_scale):
+    """The conv3 product of the training step runs, by default, as three products of float16 pieces with both operands
+    scaled by powers of two into float16's range (conv3_pool_train_h3_kernel); PNGPD_TRAIN_CONV3=x6 selects six
+    products of bfloat16 pieces, =f32 the float32 matrix instruction.  All three from the same state on the same
+    batch, with conv2's BatchNorm scale and conv3's weights moved by `act_scale` / `w_scale` so that activations up to
+    several 1e5 and weight rows down to 1e-6 pass through the scaling: the STN's pooled maxima agree to 2e-6 of their
+    largest entry (the float32 rounding of a 128-term sum), the trunk's to 2e-5, log-probabilities and transform to 2e-5."""
+    from pointnetgpd_amd import training
+    B, P, k = 24, 750, 2
+    x = torch.from_numpy(synth.candidate_points(55, B, P)).cuda()
+    sd = synth.torch_state_dict(31, k, 0.02)
+    for pre in ("feat.stn.", "feat."):
+        sd[pre + "bn2.weight"] = sd[pre + "bn2.weight"] * act_scale
+        sd[pre + "bn2.bias"] = sd[pre + "bn2.bias"] * act_scale
+        sd[pre + "conv3.weight"] = sd[pre + "conv3.weight"] * w_scale
+    out = {}
+    for variant in ("f32", "x6", "h3"):
+        monkeypatch.setenv("PNGPD_TRAIN_CONV3", variant)
+        m = PointNetCls(P, 3, k)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().train()
+        logp, trans, ws, _ = training.train_forward(m, x)
+        torch.cuda.synchronize()
+        out[variant] = {"logp": logp.double().cpu(), "trans": trans.double().cpu()}
+        for name in ("stn_pooled", "trunk_pooled"):
+            out[variant][name] = training.saved_activation(ws, B, P, k, name).double().cpu().clone()
+        assert torch.isfinite(out[variant]["logp"]).all(), variant
+    for variant in ("x6", "h3"):
+        for name in ("stn_pooled", "trunk_pooled"):
+            ref, got = out["f32"][name], out[variant][name]
+            rel = ((got - ref).abs().max() / ref.abs().max()).item()
+            print(f"{variant} {name}: max difference relative to the largest entry {rel:.2e}")
+            # the trunk's maxima also carry the difference of the 3x3 transform, itself the output of the STN's maxima
+            # through two train-mode BatchNorms over 24 rows
+            assert rel <= (2e-6 if name == "stn_pooled" else 2e-5), (variant, name, rel)
+        assert (out[variant]["logp"] - out["f32"]["logp"]).abs().max().item() <= 2e-5
+        assert (out[variant]["trans"] - out["f32"]["trans"]).abs().max().item() <= 2e-5
