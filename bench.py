@@ -328,6 +328,15 @@ def _train_roofline(conv3_tf, conv3_ms, conv3_flop, B, P):
             "flop_per_launch": conv3_flop, "executed_16bit_tflops": round(mult * conv3_tf, 1) if mult else None}
 
 
+def _voxel_traffic(S, n):
+    tpath = os.path.join(ROOT, "profiles", "r3_voxel_traffic.json")
+    if os.path.exists(tpath):
+        t = json.load(open(tpath))
+        if t["config"] == {"S": S, "n": n}:
+            return t["hbm_bytes_per_call"]
+    return None
+
+
 def voxel_workload(args, dev, rank, n_gpus, dist):
     """Scene pre-processing in front of the crop: voxel down-sampling of a 1M-point scene at n=500."""
     from pointnetgpd_amd import voxel as hv
@@ -371,11 +380,12 @@ def voxel_workload(args, dev, rank, n_gpus, dist):
                        "ms_per_call_with_host_read_of_count": round(with_host_read_ms, 4),
                        "algorithmic_GBps": round((S * 12 + M * 12) / (ms * 1e-3) / 1e9, 2),
                        "bitmap_GBps": round(gbps, 2)},
-            # whole call (six kernels) against the HBM roofline; bytes = points in (twice: bounds, marking), centres
-            # out, and the occupancy bitmap written, counted and expanded
+            # whole call (five kernels) against the HBM roofline; bytes = points in (twice: bounds, marking), centres
+            # out, and the occupancy bitmap written, counted and expanded; traffic = HBM bytes per call from the
+            # committed counter passes, when they ran this size
             "roofline": {"bound": "hbm", "kernel": "get_voxel_fun (all kernels of the call)", "achieved": round(gbps, 2),
-                         "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": None,
-                         "bytes_per_call": S * 12 + M * 12 + 3 * bitmap},
+                         "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4),
+                         "traffic": _voxel_traffic(S, n), "bytes_per_call": S * 12 + M * 12 + 3 * bitmap},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             from oracle import voxel_oracle as vo
