@@ -301,7 +301,7 @@ def _train_roofline(conv3_tf, conv3_ms, conv3_flop, B, P):
     """Roofline entry of the training step's dominant kernel, the fused conv3 product / max / arg-max.  Its default
     form computes float32-grade products on the 16-bit matrix pipe: every operand is split into two float16 pieces
     (power-of-two scaled into float16's range) and three piece products are accumulated, so a launch executes 3 x the
-    algorithmic flops on v_mfma_f32_32x32x16_f16.  `achieved` is algorithmic flops over time, as for every other line;
+    algorithmic flops on v_mfma_f32_16x16x32_f16.  `achieved` is algorithmic flops over time, as for every other line;
     `peak` is what the pipe can deliver of such products, the dense 16-bit peak / 3.  PNGPD_TRAIN_CONV3=x6 selects six
     products of bfloat16 pieces (peak / 6), =f32 the float32 matrix instruction (peak 157.3)."""
     mode = os.environ.get("PNGPD_TRAIN_CONV3", "")
@@ -313,11 +313,11 @@ def _train_roofline(conv3_tf, conv3_ms, conv3_flop, B, P):
                   "v_mfma_f32_32x32x16_bf16; peak = dense bf16 peak / 6)")
     else:
         peak, mult = round(PEAK_TFLOPS["bf16"] / 3.0, 1), 3.0
-        kernel = ("conv3_pool_train_h3_kernel (float32-grade products as 3 float16 piece products on "
-                  "v_mfma_f32_32x32x16_f16; peak = dense 16-bit peak / 3)")
+        kernel = ("conv3_pool_train_ws_kernel (float32-grade products as 3 float16 piece products on "
+                  "v_mfma_f32_16x16x32_f16, weights stationary; peak = dense 16-bit peak / 3)")
     # HBM bytes per launch from the committed PMC passes, when they ran this kernel at this size
     traffic = None
-    tname = "r3_train_conv3_h3_traffic.json" if mult == 3.0 else "r2_train_conv3_traffic.json"
+    tname = "r3_train_conv3_ws_traffic.json" if mult == 3.0 else "r2_train_conv3_traffic.json"
     tpath = os.path.join(ROOT, "profiles", tname)
     if os.path.exists(tpath) and mult is not None:
         t = json.load(open(tpath))

@@ -400,11 +400,11 @@ __device__ __forceinline__ int w3s_index(int c, int k) {
     return (((nt * 8 + ks) * 3) * 64 + r + 32 * hh) * 8 + j;
 }
 
-// Index of piece 0 (hi) of W3[c][k] in the split-float16 image: [nt 32][ks 8][piece 2][lane 64][8], the B fragments of
-// v_mfma_f32_32x32x16_f16 (same lane map as the bfloat16 image).  The two pieces are 512 values apart.
-__device__ __forceinline__ int w3h_index(int c, int k) {
-    const int nt = c >> 5, r = c & 31, ks = k >> 4, hh = (k >> 3) & 1, j = k & 7;
-    return (((nt * 8 + ks) * 2) * 64 + r + 32 * hh) * 8 + j;
+// Index of piece 0 (hi) of W3[c][k] in the split-float16 image: [ct 64][ks 4][piece 2][lane 64][8], the B fragments of
+// v_mfma_f32_16x16x32_f16; lane l holds channel 16ct + l%16 and k = 32ks + 8(l/16) + j.  The two pieces are 512 values apart.
+__device__ __forceinline__ int w3h16_index(int c, int k) {
+    const int ct = c >> 4, cl = c & 15, ks = k >> 5, q = (k >> 3) & 3, j = k & 7;
+    return (((ct * 4 + ks) * 2) * 64 + cl + 16 * q) * 8 + j;
 }
 
 // The power of two that moves m (>= 0) into [2^13, 2^14); 1 for m = 0 or not finite.  Clamped so that the factor and
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restric
     const float wv = wf * s_sc;
     w3p[w3p_index(c, i)] = wv;
     if (w3s != nullptr && wsc != nullptr) {
-        // The same weight as TWO float16 pieces (conv3_pool_train_h3_kernel): the channel's row is first scaled by a
+        // The same weight as TWO float16 pieces (conv3_pool_train_ws_kernel): the channel's row is first scaled by a
         // power of two that puts its largest entry in [2^13, 2^14) - float16 has 11 significand bits but only 5
         // exponent bits - so that hi + lo carries 22 bits of every entry within 2^17 of the largest; wsc[c] undoes it.
         float m = fabsf(wv);
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restric
         const float ws = wv * up;
         const _Float16 hi = (_Float16)ws;
         const _Float16 lo = (_Float16)(ws - (float)hi);
-        const int base = w3h_index(c, i);
+        const int base = w3h16_index(c, i);
         w3s[base] = __builtin_bit_cast(unsigned short, hi);
         w3s[base + 512] = __builtin_bit_cast(unsigned short, lo);
     } else if (w3s != nullptr) {
@@ -806,171 +806,242 @@ __global__ __launch_bounds__(TC_THREADS, 2) void conv3_pool_train_x6_kernel(cons
 // pieces for 24) and what is dropped - xl wl and the two representation remainders - is below 3 * 2^-22 of the product:
 // the size of the float32 accumulation's own rounding over 128 terms.  Half the MFMAs of the six-product kernel.
 // float16 has only 5 exponent bits, so both operands are scaled by powers of two first (exact): a weight row by the
-// factor that k_conv3_stats_pack chose for its channel (largest entry in [2^13, 2^14)), the 64 points a wave holds in a
-// pass by the factor that does the same for the largest activation among them.  Entries within 2^17 of the largest keep
-// all 22 bits; smaller ones lose low bits whose weight is below 2^-39 of the largest entry.  A product of two scaled
-// operands is below 2^28 and a sum of 128 below 2^35.  The maxima of a pass are compared in the scaled domain (one
-// positive factor per wave, pass and channel) and descaled before they meet the maxima of other passes and waves.
-// Same grid and epilogue as the kernels above; a weight chunk is a whole 32-channel tile (16 KiB).
+// factor that k_conv3_stats_pack chose for its channel (largest entry in [2^13, 2^14)), a tile of 16 points by the
+// factor that does the same for its largest activation.  Entries within 2^17 of the largest keep all 22 bits; smaller
+// ones lose low bits whose weight is below 2^-39 of the largest entry.  A product of two scaled operands is below 2^28
+// and a sum of 128 below 2^35.  A block's maximum is found in the scaled domain and descaled (exactly) before it
+// meets the running maximum.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-constexpr int TH_CHUNK_BYTES = 16384;    // a 32-channel tile: 8 k-steps x 2 pieces x 1 KiB
 
-__device__ __forceinline__ void th_dma_chunk(const char* src, char* dst, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave * 4 + i;
-        __builtin_amdgcn_global_load_lds((const void*)(src + piece * 1024 + lane * 16), (lds_void*)(dst + piece * 1024),
-                                         16, 0, 0);
-    }
-}
+// The kernel keeps the WEIGHTS stationary (the scoring kernels' structure, conv_stack_x3.hip): a
+// workgroup of 8 waves owns one candidate and 512 channels; wave w keeps both float16 pieces of channels
+// [64w, 64w + 64) of that half in 128 registers for the whole kernel (4 tiles of 16 channels x 4 k-steps of 32 x 2
+// pieces, v_mfma_f32_16x16x32_f16), so no weight ever passes through LDS and no barrier paces the MFMAs.  What moves
+// through LDS is the points: tiles of 16 rows of h, scaled by the power of two that puts the tile's largest entry in
+// [2^13, 2^14), split into the two pieces and stored in A-fragment order (8 KiB a tile, 8 tiles a batch, two batches
+// in LDS); wave w makes tile w of the NEXT batch in the second half of the consume loop - its rows were requested at the
+// top of the batch - two waves of different SIMDs per tile step.  One barrier per 128 points.
+// Every wave multiplies every tile with its channels (a chain of 12 MFMAs per 16 x 16 block accumulating in place),
+// finds the block's largest value and its row, descales it (tile factor x channel factor: exact) and compares it with
+// the lane's running maximum; tiles come in ascending order of their points, so a strict compare keeps the first
+// maximum, as max_pool1d does.
+constexpr int TW_WAVES = 8, TW_THREADS = TW_WAVES * 64;
+constexpr int TW_PLANE_BYTES = 4096;                       // [ks 4][lane 64][16 B]
+constexpr int TW_TILE_BYTES = 2 * TW_PLANE_BYTES;
+constexpr int TW_BATCH_TILES = TW_WAVES;
+constexpr int TW_BATCH_BYTES = TW_BATCH_TILES * TW_TILE_BYTES;
+constexpr int TW_OFF_SCALE = 2 * TW_BATCH_BYTES;           // [2][8] floats: the factor that undoes a tile's scaling
+constexpr int TW_LDS_BYTES = TW_OFF_SCALE + 2 * TW_BATCH_TILES * 4;
+constexpr int TW_NT = 4;                                   // channel tiles of 16 per wave
 
-__global__ __launch_bounds__(TC_THREADS, 2) void conv3_pool_train_h3_kernel(const float* __restrict__ h,
-                                                                            const unsigned short* __restrict__ w3h,
-                                                                            const float* __restrict__ wsc,
-                                                                            const float* __restrict__ sh, int P,
-                                                                            int relu, int ntb,
-                                                                            float* __restrict__ pooled,
-                                                                            int* __restrict__ arg) {
+__global__ __launch_bounds__(TW_THREADS) void conv3_pool_train_ws_kernel(const float* __restrict__ h,
+                                                                         const unsigned short* __restrict__ w3h,
+                                                                         const float* __restrict__ wsc,
+                                                                         const float* __restrict__ sh, int B, int P,
+                                                                         int relu, float* __restrict__ pooled,
+                                                                         int* __restrict__ arg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.x, nt0 = blockIdx.y * ntb;
-    const int nch = 32 * ntb;
-    char* s_w3 = smem;
-    float* s_red = (float*)(smem + 2 * TH_CHUNK_BYTES);      // [4][nch]
-    int* s_arg = (int*)(s_red + TC_WAVES * nch);             // [4][nch]
-    float* s_wsc = (float*)(s_arg + TC_WAVES * nch);         // [nch]
-    const char* g_w3 = (const char*)w3h + (size_t)nt0 * TH_CHUNK_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    // Workgroups are handed to the 8 XCDs in turn: the two channel halves of a candidate are workgroups L and L + 8, so
+    // they run on the same XCD one after the other and the second finds the candidate's rows in that XCD's L2
+    // (as (candidate, half) = (blockIdx.x, blockIdx.y) they were 256 workgroups apart: 201 MB fetched per launch for
+    // 98 MB of rows)
+    const int L = blockIdx.x;
+    const int b = (L >> 4) * 8 + (L & 7), half = (L >> 3) & 1;
+    if (b >= B) return;
+    float* s_scale = (float*)(smem + TW_OFF_SCALE);
 
-    th_dma_chunk(g_w3, s_w3, wave, lane);
-    for (int c = tid; c < TC_WAVES * nch; c += TC_THREADS) {
-        s_red[c] = -INFINITY;
-        s_arg[c] = 0;
+    const int ct0 = (half * TW_WAVES + wave) * TW_NT;                 // first channel tile of this wave
+    f16x8 bwh[TW_NT][4], bwl[TW_NT][4];
+    float cdescale[TW_NT];
+#pragma unroll
+    for (int nt = 0; nt < TW_NT; ++nt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const size_t at = (size_t)((((ct0 + nt) * 4 + ks) * 2) * 64 + lane) * 16;
+            bwh[nt][ks] = *(const f16x8*)((const char*)w3h + at);
+            bwl[nt][ks] = *(const f16x8*)((const char*)w3h + at + 1024);
+        }
+        cdescale[nt] = wsc[16 * (ct0 + nt) + c];
     }
-    for (int c = tid; c < nch; c += TC_THREADS) s_wsc[c] = wsc[32 * nt0 + c];
-    lds_dma_wait();
+
+    const int ntiles = (P + 15) >> 4;
+    const int nbatch = (ntiles + TW_BATCH_TILES - 1) / TW_BATCH_TILES;
+    const float* hb = h + (size_t)b * P * C2;
+
+    // rows of the tile this wave makes next: lane (c, q) holds k = 32ks + 8q .. + 7 of row c
+    f32x4 st[4][2];
+    auto fetch_tile = [&](int tile) {
+        int pt = tile * 16 + c;
+        pt = pt < P ? pt : P - 1;                               // rows beyond P repeat the last point
+        const float* hp = hb + (size_t)pt * C2 + 8 * q;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            st[ks][0] = *(const f32x4*)(hp + 32 * ks);
+            st[ks][1] = *(const f32x4*)(hp + 32 * ks + 4);
+        }
+    };
+    auto make_tile = [&](char* dst, float* scale_slot) {
+        float m = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = __builtin_fmaxf(m, __builtin_fabsf(st[ks][j >> 2][j & 3]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off));
+        const float up = pow2_scale_to_2p13(m);
+        if (lane == 0) *scale_slot = 1.0f / up;                  // a power of two: exact
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f16x8 xh, xl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = st[ks][j >> 2][j & 3] * up;
+                const _Float16 hi = (_Float16)x;
+                xh[j] = hi;
+                xl[j] = (_Float16)(x - (float)hi);
+            }
+            *(f16x8*)(dst + (ks * 64 + lane) * 16) = xh;
+            *(f16x8*)(dst + TW_PLANE_BYTES + (ks * 64 + lane) * 16) = xl;
+        }
+    };
+
+    fetch_tile(wave);
+    make_tile(smem + wave * TW_TILE_BYTES, s_scale + wave);
     __syncthreads();
 
-    float* s_red_wave = s_red + wave * nch;
-    int* s_arg_wave = s_arg + wave * nch;
-    const int pts_per_pass = TC_WAVES * 32 * TC_MT;
-    const int npass = (P + pts_per_pass - 1) / pts_per_pass;
-
-    for (int pass = 0; pass < npass; ++pass) {
-        // A operands: piece [mt][ks] of lane (r, hh) holds k = 16ks + 8hh + j of point r of tile mt
-        f16x8 Ah[TC_MT][8], Al[TC_MT][8];
-        const int pt_base = pass * pts_per_pass + wave * TC_MT * 32;
-        float xdescale;
-        {
-            f32x4 v[TC_MT][8][2];
-            float m = 0.f;
+    float bv[TW_NT];
+    int bi[TW_NT];
 #pragma unroll
-            for (int mt = 0; mt < TC_MT; ++mt) {
-                int pt = pt_base + mt * 32 + r;
-                pt = pt < P ? pt : P - 1;                   // duplicates of the last point cannot change a maximum
-                const float* hp = h + ((size_t)b * P + pt) * C2 + 8 * hh;
+    for (int nt = 0; nt < TW_NT; ++nt) {
+        bv[nt] = -INFINITY;
+        bi[nt] = 0;
+    }
+    // A fragments of the tile being multiplied, refilled IN PLACE for the next tile inside the last chain of a tile:
+    // the lo plane when its four MFMAs have been issued, each hi fragment behind its last MFMA (a second set of 32
+    // registers does not fit beside 128 of weights and 32 of rows in flight)
+    f16x8 ah[4], al[4];
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    v[mt][ks][0] = *(const f32x4*)(hp + 16 * ks);
-                    v[mt][ks][1] = *(const f32x4*)(hp + 16 * ks + 4);
-                }
+    for (int ks = 0; ks < 4; ++ks) {
+        ah[ks] = *(const f16x8*)(smem + (ks * 64 + lane) * 16);
+        al[ks] = *(const f16x8*)(smem + TW_PLANE_BYTES + (ks * 64 + lane) * 16);
+    }
+    auto search = [&](const f32x4& z, int nt, float descale, int row0) {
+        // register i is row 4q + i of the tile, channel c of the channel tile: ascending i is ascending point
+        float m = z[0];
+        int mi = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (z[i] > m) {
+                m = z[i];
+                mi = i;
             }
-#pragma unroll
-            for (int mt = 0; mt < TC_MT; ++mt)
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) m = __builtin_fmaxf(m, __builtin_fabsf(v[mt][ks][j >> 2][j & 3]));
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off));
-            const float up = pow2_scale_to_2p13(m);
-            xdescale = 1.0f / up;                          // a power of two: exact
-#pragma unroll
-            for (int mt = 0; mt < TC_MT; ++mt)
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float x = v[mt][ks][j >> 2][j & 3] * up;
-                        const _Float16 xh = (_Float16)x;
-                        Ah[mt][ks][j] = xh;
-                        Al[mt][ks][j] = (_Float16)(x - (float)xh);
-                    }
+        m *= descale * cdescale[nt];                             // powers of two: exact
+        if (m > bv[nt]) {                                        // later tiles hold later points: strict compare
+            bv[nt] = m;
+            bi[nt] = row0 + mi;
         }
-        const bool last_pass = (pass == npass - 1);
-        for (int nt = 0; nt < ntb; ++nt) {
-            f32x16 acc[TC_MT];
+        // opaque to the optimiser: in the unrolled batch it otherwise merges the compare chains of all tiles into one
+        // tree at the end of the batch and keeps every accumulator alive (in scratch memory) until then
+        asm volatile("" : "+v"(bv[nt]), "+v"(bi[nt]));
+    };
+    f32x4 zp = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};     // before the first block: never beats a maximum
+    float zp_descale = 1.0f;
+    int zp_row0 = 0;
+    for (int bt = 0; bt < nbatch; ++bt) {
+        const int buf = bt & 1;
+        const char* cur = smem + buf * TW_BATCH_BYTES;
+        const bool more = bt + 1 < nbatch;
+        if (more) fetch_tile((bt + 1) * TW_BATCH_TILES + wave);
 #pragma unroll
-            for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = f32x16{0};
-            if (!(last_pass && nt == ntb - 1)) {
-                const int nxt = nt + 1 < ntb ? nt + 1 : 0;
-                th_dma_chunk(g_w3 + (size_t)nxt * TH_CHUNK_BYTES, s_w3 + ((nt + 1) & 1) * TH_CHUNK_BYTES, wave, lane);
-            }
-            const char* buf = s_w3 + (nt & 1) * TH_CHUNK_BYTES;
+        for (int t = 0; t < TW_BATCH_TILES; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            // waves 2j and 2j + 1 (different SIMDs) make their tiles in front of tile 4 + j: the rows were requested at
+            // the top of the batch, four tiles of MFMAs earlier (made in front of tile `wave`, wave 0 waited for memory
+            // at the start of every batch and the other seven for wave 0 at its end)
+            if (more && t == 4 + (wave >> 1))
+                make_tile(smem + (buf ^ 1) * TW_BATCH_BYTES + wave * TW_TILE_BYTES, s_scale + (buf ^ 1) * TW_BATCH_TILES + wave);
+            // the tile multiplied after this one: tile 0 of the next batch behind the last (its buffer is complete only
+            // behind the barrier, so that refill waits for it - see below)
+            const char* nxt = t + 1 < TW_BATCH_TILES ? cur + (t + 1) * TW_TILE_BYTES : nullptr;
+            const float tdescale = s_scale[buf * TW_BATCH_TILES + t];
+            const int row0 = (bt * TW_BATCH_TILES + t) * 16 + 4 * q;
+            __builtin_amdgcn_sched_barrier(0);
+            // The search of a block (~13 vector instructions that read the chain's result) is issued behind the MFMAs of
+            // the FOLLOWING block, when that result has long been written: placed right behind its own chain, a wave
+            // waits out the chain's latency twelve MFMAs at a time.  zp / zp_descale / zp_row0 carry the previous block.
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const f16x8 bh = *(const f16x8*)(buf + ((ks * 2 + 0) * 64 + lane) * 16);
-                const f16x8 bl = *(const f16x8*)(buf + ((ks * 2 + 1) * 64 + lane) * 16);
+            for (int nt = 0; nt < TW_NT - 1; ++nt) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 // smallest products first
 #pragma unroll
-                for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[mt][ks], bh, acc[mt], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bwh[nt][ks], z, 0, 0, 0);
 #pragma unroll
-                for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[mt][ks], bl, acc[mt], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bwl[nt][ks], z, 0, 0, 0);
 #pragma unroll
-                for (int mt = 0; mt < TC_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[mt][ks], bh, acc[mt], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bwh[nt][ks], z, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                search(zp, (nt + TW_NT - 1) % TW_NT, nt == 0 ? zp_descale : tdescale, nt == 0 ? zp_row0 : row0);
+                __builtin_amdgcn_sched_barrier(0);
+                zp = z;
             }
-            lds_dma_wait();             // the chunk issued at the top of this tile landed long ago, behind the MFMAs
-            __syncthreads();
-            // accumulator register i of lane half hh is point (i&3) + 8(i>>2) + 4hh of the tile, channel 32nt + r:
-            // ascending i is ascending point index, so a strict compare keeps the first maximum.  (Hiding this search
-            // under the MFMAs of the next tile - two accumulator sets, the search cut into eight parts between the
-            // k-steps - was measured: 1.635 ms per step either way.)
-            float bv = -INFINITY;
-            int bi = 0;
+            {
+                constexpr int nt = TW_NT - 1;
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mt = 0; mt < TC_MT; ++mt) {
-                const int base = pt_base + mt * 32 + 4 * hh;
+                for (int ks = 0; ks < 4; ++ks) z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bwh[nt][ks], z, 0, 0, 0);
+                if (nxt != nullptr) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float v = acc[mt][i];
-                    const int idx = base + (i & 3) + 8 * (i >> 2);
-                    if (v > bv) {
-                        bv = v;
-                        bi = idx;
-                    }
+                    for (int ks = 0; ks < 4; ++ks) al[ks] = *(const f16x8*)(nxt + TW_PLANE_BYTES + (ks * 64 + lane) * 16);
                 }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bwl[nt][ks], z, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bwh[nt][ks], z, 0, 0, 0);
+                    if (nxt != nullptr) ah[ks] = *(const f16x8*)(nxt + (ks * 64 + lane) * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                search(zp, nt - 1, tdescale, row0);
+                __builtin_amdgcn_sched_barrier(0);
+                zp = z;
+                zp_descale = tdescale;
+                zp_row0 = row0;
             }
-            bi = bi < P ? bi : P - 1;
-            const float ov = __shfl_xor(bv, 32);
-            const int oi = __shfl_xor(bi, 32);
-            if (ov > bv || (ov == bv && oi < bi)) {
-                bv = ov;
-                bi = oi;
-            }
-            bv *= xdescale * s_wsc[32 * nt + r];            // powers of two: the product and the scaling are exact
-            if (hh == 0 && bv > s_red_wave[32 * nt + r]) {   // later passes hold later points: strict compare
-                s_red_wave[32 * nt + r] = bv;
-                s_arg_wave[32 * nt + r] = bi;
+        }
+        __syncthreads();
+        if (more) {
+            const char* first = smem + (buf ^ 1) * TW_BATCH_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                ah[ks] = *(const f16x8*)(first + (ks * 64 + lane) * 16);
+                al[ks] = *(const f16x8*)(first + TW_PLANE_BYTES + (ks * 64 + lane) * 16);
             }
         }
     }
-    __syncthreads();
-    for (int c = tid; c < nch; c += TC_THREADS) {
-        float bv = s_red[c];
-        int bi = s_arg[c];
+    search(zp, TW_NT - 1, zp_descale, zp_row0);
+    // the four row groups q of a channel; the lowest point wins a tie
 #pragma unroll
-        for (int w = 1; w < TC_WAVES; ++w) {
-            const float v = s_red[w * nch + c];
-            const int i = s_arg[w * nch + c];
-            if (v > bv || (v == bv && i < bi)) {
-                bv = v;
-                bi = i;
+    for (int nt = 0; nt < TW_NT; ++nt) {
+        float v = bv[nt];
+        int i = bi[nt] < P ? bi[nt] : P - 1;
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float ov = __shfl_xor(v, off);
+            const int oi = __shfl_xor(i, off);
+            if (ov > v || (ov == v && oi < i)) {
+                v = ov;
+                i = oi;
             }
         }
-        const int ch = 32 * nt0 + c;
-        bv += sh[ch];
-        pooled[(size_t)b * C3 + ch] = relu ? __builtin_fmaxf(bv, 0.f) : bv;
-        arg[(size_t)b * C3 + ch] = bi;
+        const int ch = 16 * (ct0 + nt) + c;
+        v += sh[ch];
+        if (q == 0) {
+            pooled[(size_t)b * C3 + ch] = relu ? __builtin_fmaxf(v, 0.f) : v;
+            arg[(size_t)b * C3 + ch] = i;
+        }
     }
 }
 
@@ -1237,8 +1308,9 @@ hipError_t t_conv3_fwd(float* h2, const float* W3, const float* b3, const float*
     // 32x32 blocks of a partial that its kernel wrote (bit 4 i + j)
     hipLaunchKernelGGL(k_gram_finalize, dim3(C2 * C2 / 16), dim3(256), 0, s, (const double*)gram_part, chunks,
                        (const double*)w.abar_d, M, w.cov, gram_f64 ? 0xCCFFu : 0xAC6Fu);
-    // PNGPD_TRAIN_CONV3 selects the instruction of the product/max kernel: f32 (v_mfma_f32_32x32x2_f32), x6 (six products of
-    // bfloat16 pieces), default h3 (three products of float16 pieces); read at every call, like PNGPD_TRAIN_GRAM above
+    // PNGPD_TRAIN_CONV3 selects the product/max kernel: f32 (v_mfma_f32_32x32x2_f32), x6 (six products of bfloat16 pieces),
+    // default: three products of float16 pieces with the weights stationary in registers; read at every call, like
+    // PNGPD_TRAIN_GRAM above
     const char* conv3_env = getenv("PNGPD_TRAIN_CONV3");
     const bool use_f32 = (conv3_env && conv3_env[0] == 'f') || w.w3s == nullptr;
     const bool use_x6 = !use_f32 && ((conv3_env && conv3_env[0] == 'x') || w.wsc == nullptr);
@@ -1263,13 +1335,13 @@ hipError_t t_conv3_fwd(float* h2, const float* W3, const float* b3, const float*
         hipLaunchKernelGGL(conv3_pool_train_kernel, dim3(B, cs), dim3(TC_THREADS), lds, s, h2, (const float*)w.w3p,
                            (const float*)w.sh, P, relu_out, ntb, pooled, arg);
     } else if (!use_x6) {
-        const size_t lds = 2 * TH_CHUNK_BYTES + (size_t)TC_WAVES * 32 * ntb * 8 + (size_t)32 * ntb * 4;
-        e = hipFuncSetAttribute((const void*)conv3_pool_train_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
+        e = hipFuncSetAttribute((const void*)conv3_pool_train_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                TW_LDS_BYTES);
         if (e != hipSuccess) return e;
         if (w.ev_begin != nullptr && (e = hipEventRecord(w.ev_begin, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(conv3_pool_train_h3_kernel, dim3(B, cs), dim3(TC_THREADS), lds, s, h2,
-                           (const unsigned short*)w.w3s, (const float*)w.wsc, (const float*)w.sh, P, relu_out, ntb, pooled,
+        static_assert(C3 / (TW_WAVES * TW_NT * 16) == 2, "two channel halves per candidate");
+        hipLaunchKernelGGL(conv3_pool_train_ws_kernel, dim3((B + 7) / 8 * 16), dim3(TW_THREADS), TW_LDS_BYTES, s, h2,
+                           (const unsigned short*)w.w3s, (const float*)w.wsc, (const float*)w.sh, B, P, relu_out, pooled,
                            arg);
     } else {
         const size_t lds = 2 * TX_CHUNK_BYTES + (size_t)TC_WAVES * 32 * ntb * 8;

@@ -525,7 +525,7 @@ def test_gram_on_bf16_pieces_agrees_with_the_float64_gram(monkeypatch):
 @pytest.mark.parametrize("act_scale,w_scale", [(1.0, 1.0), (3.0e3, 2.0e-4), (1.0e-3, 5.0e2), (6.0e4, 1.0)])
 def test_conv3_on_float16_pieces_agrees_with_the_other_products(monkeypatch, act_scale, w_scale):
     """The conv3 product of the training step runs, by default, as three products of float16 pieces with both operands
-    scaled by powers of two into float16's range (conv3_pool_train_h3_kernel); PNGPD_TRAIN_CONV3=x6 selects six
+    scaled by powers of two into float16's range (conv3_pool_train_ws_kernel); PNGPD_TRAIN_CONV3=x6 selects six
     products of bfloat16 pieces, =f32 the float32 matrix instruction.  All three from the same state on the same
     batch, with conv2's BatchNorm scale and conv3's weights moved by `act_scale` / `w_scale` so that activations up to
     several 1e5 and weight rows down to 1e-6 pass through the scaling: the STN's pooled maxima agree to 2e-6 of their
@@ -539,8 +539,11 @@ def test_conv3_on_float16_pieces_agrees_with_the_other_products(monkeypatch, act
         sd[pre + "bn2.bias"] = sd[pre + "bn2.bias"] * act_scale
         sd[pre + "conv3.weight"] = sd[pre + "conv3.weight"] * w_scale
     out = {}
-    for variant in ("f32", "x6", "h3"):
-        monkeypatch.setenv("PNGPD_TRAIN_CONV3", variant)
+    for variant in ("f32", "x6", "f16"):
+        if variant == "f16":
+            monkeypatch.delenv("PNGPD_TRAIN_CONV3", raising=False)       # the default
+        else:
+            monkeypatch.setenv("PNGPD_TRAIN_CONV3", variant)
         m = PointNetCls(P, 3, k)
         m.load_state_dict(sd, strict=True)
         m = m.cuda().train()
@@ -550,7 +553,7 @@ def test_conv3_on_float16_pieces_agrees_with_the_other_products(monkeypatch, act
         for name in ("stn_pooled", "trunk_pooled"):
             out[variant][name] = training.saved_activation(ws, B, P, k, name).double().cpu().clone()
         assert torch.isfinite(out[variant]["logp"]).all(), variant
-    for variant in ("x6", "h3"):
+    for variant in ("x6", "f16"):
         for name in ("stn_pooled", "trunk_pooled"):
             ref, got = out["f32"][name], out[variant][name]
             rel = ((got - ref).abs().max() / ref.abs().max()).item()
