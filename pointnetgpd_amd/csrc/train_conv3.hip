@@ -834,6 +834,23 @@ constexpr int TW_OFF_SCALE = 2 * TW_BATCH_BYTES;           // [2][8] floats: the
 constexpr int TW_LDS_BYTES = TW_OFF_SCALE + 2 * TW_BATCH_TILES * 4;
 constexpr int TW_NT = 4;                                   // channel tiles of 16 per wave
 
+// Diagnostic build only (-DPNGPD_STAMPS, tools/diag/tw_stamps.py): shader-clock stamps of workgroup 0; no output value
+// depends on them and the product build compiles none of it.
+#ifdef PNGPD_STAMPS
+constexpr int TW_STAMP_BATCHES = 6, TW_STAMP_EVENTS = 11;    // batch start, behind each of 8 tiles, barrier, behind it
+__device__ unsigned long long g_tw_stamps[TW_WAVES][TW_STAMP_BATCHES * TW_STAMP_EVENTS];
+extern "C" int pngpd_debug_read_tw_stamps(unsigned long long* stamps) {
+    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_tw_stamps), sizeof(g_tw_stamps));
+}
+#define TW_STAMP(bt, ev)                                                                                   \
+    do {                                                                                                   \
+        if (blockIdx.x == 0 && lane == 0 && (bt) < TW_STAMP_BATCHES)                                       \
+            g_tw_stamps[wave][(bt) * TW_STAMP_EVENTS + (ev)] = __builtin_amdgcn_s_memtime();               \
+    } while (0)
+#else
+#define TW_STAMP(bt, ev)
+#endif
+
 __global__ __launch_bounds__(TW_THREADS) void conv3_pool_train_ws_kernel(const float* __restrict__ h,
                                                                          const unsigned short* __restrict__ w3h,
                                                                          const float* __restrict__ wsc,
@@ -954,10 +971,12 @@ __global__ __launch_bounds__(TW_THREADS) void conv3_pool_train_ws_kernel(const f
         const int buf = bt & 1;
         const char* cur = smem + buf * TW_BATCH_BYTES;
         const bool more = bt + 1 < nbatch;
+        TW_STAMP(bt, 0);
         if (more) fetch_tile((bt + 1) * TW_BATCH_TILES + wave);
 #pragma unroll
         for (int t = 0; t < TW_BATCH_TILES; ++t) {
             __builtin_amdgcn_sched_barrier(0);
+            if (t > 0) TW_STAMP(bt, t);
             // waves 2j and 2j + 1 (different SIMDs) make their tiles in front of tile 4 + j: the rows were requested at
             // the top of the batch, four tiles of MFMAs earlier (made in front of tile `wave`, wave 0 waited for memory
             // at the start of every batch and the other seven for wave 0 at its end)
@@ -1011,7 +1030,9 @@ __global__ __launch_bounds__(TW_THREADS) void conv3_pool_train_ws_kernel(const f
                 zp_row0 = row0;
             }
         }
+        TW_STAMP(bt, 8);
         __syncthreads();
+        TW_STAMP(bt, 9);
         if (more) {
             const char* first = smem + (buf ^ 1) * TW_BATCH_BYTES;
 #pragma unroll
