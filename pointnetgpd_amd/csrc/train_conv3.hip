@@ -988,9 +988,11 @@ __global__ __launch_bounds__(TW_THREADS) void conv3_pool_train_ws_kernel(const f
             const float tdescale = s_scale[buf * TW_BATCH_TILES + t];
             const int row0 = (bt * TW_BATCH_TILES + t) * 16 + 4 * q;
             __builtin_amdgcn_sched_barrier(0);
-            // The search of a block (~13 vector instructions that read the chain's result) is issued behind the MFMAs of
-            // the FOLLOWING block, when that result has long been written: placed right behind its own chain, a wave
-            // waits out the chain's latency twelve MFMAs at a time.  zp / zp_descale / zp_row0 carry the previous block.
+            // The search of a block (17 vector instructions that read the chain's result) goes with the MFMAs of the
+            // FOLLOWING block, when that result has long been written, and in one scheduling region with them, so that
+            // the scheduler fills the hazard slots between a compare and its select with MFMAs (fenced off behind the
+            // chain: +1.4 % kernel time; pinned one MFMA : two vector instructions: no gain over the scheduler's own
+            // order).  zp / zp_descale / zp_row0 carry the previous block.
 #pragma unroll
             for (int nt = 0; nt < TW_NT - 1; ++nt) {
                 f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -1001,7 +1003,6 @@ __global__ __launch_bounds__(TW_THREADS) void conv3_pool_train_ws_kernel(const f
                 for (int ks = 0; ks < 4; ++ks) z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bwl[nt][ks], z, 0, 0, 0);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bwh[nt][ks], z, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
                 search(zp, (nt + TW_NT - 1) % TW_NT, nt == 0 ? zp_descale : tdescale, nt == 0 ? zp_row0 : row0);
                 __builtin_amdgcn_sched_barrier(0);
                 zp = z;
@@ -1022,7 +1023,6 @@ __global__ __launch_bounds__(TW_THREADS) void conv3_pool_train_ws_kernel(const f
                     z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bwh[nt][ks], z, 0, 0, 0);
                     if (nxt != nullptr) ah[ks] = *(const f16x8*)(nxt + (ks * 64 + lane) * 16);
                 }
-                __builtin_amdgcn_sched_barrier(0);
                 search(zp, nt - 1, tdescale, row0);
                 __builtin_amdgcn_sched_barrier(0);
                 zp = z;
