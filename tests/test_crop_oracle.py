@@ -165,3 +165,23 @@ def test_draw_rule_and_vote_score_equal_the_reference_statements():
         assert label == int(d[f"label_{i}"])
         assert (2 if int(d[f"k_{i}"]) == 3 else 1) == int(d[f"best_{i}"])
         assert score == d[f"score_{i}"] and np.asarray(score).dtype == d[f"score_{i}"].dtype
+
+
+def test_vote_tie_rule_equals_scipy_mode_with_its_legacy_output_shape():
+    """apps/kinect2grasp.py:799 reads `mode(predict)[0][0]`.  scipy >= 1.11 returns scalars from that call (the two
+    subscripts then fail), but the same function with `keepdims=True` gives the arrays the reference indexes; its
+    tie rule — the smallest of the most frequent values — is the one the restatement and the device vote use."""
+    from scipy.stats import mode
+    rng = np.random.default_rng(11)
+    ties = 0
+    for _ in range(400):
+        k = int(rng.integers(2, 4))
+        R = int(rng.integers(1, 8))
+        preds = [int(v) for v in rng.integers(0, k, R)]
+        probs = rng.random((R, 1, k), dtype=np.float32)
+        want = int(mode(preds, keepdims=True)[0][0])
+        label, _ = co.vote(preds, probs, k)
+        assert label == want
+        counts = np.bincount(preds, minlength=k)
+        ties += int((counts == counts.max()).sum() > 1)
+    assert ties > 50
