@@ -31,6 +31,7 @@ LIB_SOURCES = [
     "voxel.hip",
     "train.hip",
     "train_conv3.hip",
+    "train_bwd2.hip",
     "tall_gemm.hip",
     "train_api.cpp",
 ]

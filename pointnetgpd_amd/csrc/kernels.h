@@ -198,6 +198,22 @@ hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean
                     float* dbeta, float* dbias_zero, hipStream_t s,
                     const float* conv1_x3 = nullptr, const float* conv1_w = nullptr, const float* conv1_b = nullptr,
                     const float* beta = nullptr);
+// t_bn_bwd of the two per-point layers in front of conv3, cut differently (train_bwd2.hip): sums of BatchNorm 2 ->
+// one pass that turns dh2 into dy2 in place, multiplies it with W2 into dh1 and leaves the partial column sums of
+// BatchNorm 1's backward in part ([tall_gemm_blocks(M)][2][64] doubles) -> the rest of the stack's backward (dW1, dX3)
+// straight from dh1, without storing dy1
+hipError_t t_bn_bwd_sums(const float* dh, const float* y, const float* mean, const float* rstd, const float* gamma,
+                         const float* beta, int M, int C, double* part, float* m1, float* m2, float* dgamma,
+                         float* dbeta, float* dbias_zero, hipStream_t s);
+hipError_t launch_conv2_bwd_fused(float* dh2, const float* y2, const float* mean2, const float* rstd2,
+                                  const float* gamma2, const float* beta2, const float* m1, const float* m2,
+                                  const float* W2, float* dh1, int M, const float* X3, const float* W1, const float* b1,
+                                  const float* mean1, const float* rstd1, const float* gamma1, const float* beta1,
+                                  double* part, hipStream_t s);
+hipError_t t_conv1_bwd_from_sums(const float* dh1, const float* X3, const float* W1, const float* b1, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, int M, double* part, int nblk,
+                                 float* m1, float* m2, float* dgamma, float* dbeta, float* dbias_zero, float* dW1,
+                                 float* dX3, hipStream_t s);
 
 // conv3 + BatchNorm (batch statistics) + max over points without the [M,1024] activation (train_conv3.hip)
 struct Conv3Ws {

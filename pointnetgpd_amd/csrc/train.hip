@@ -521,6 +521,83 @@ __global__ __launch_bounds__(256) void k_conv1_bn_bwd_dense(float* __restrict__ 
     }
 }
 
+// Everything behind conv1's BatchNorm in one pass over dh1: dy1 as in k_conv1_bn_bwd_dense, used where it is made and
+// never stored - partial sums of dW1[c,j] = sum_m dy1[m,c] X3[m,j] (part [gridDim.x][64*3] doubles, for
+// k_reduce_double) and, when dX3 is given, dX3[m,j] = sum_c dy1[m,c] W1[c,j].
+// block = 16 column quads x 16 row lanes over 256 rows.
+__global__ __launch_bounds__(256) void k_conv1_bwd_all(const float* __restrict__ dh, const float* __restrict__ X3,
+                                                       const float* __restrict__ W1, const float* __restrict__ b1,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ m1, const float* __restrict__ m2, int M,
+                                                       double* __restrict__ part, float* __restrict__ dX3) {
+    __shared__ float sw[16][64][3];
+    const int cq = threadIdx.x & 15, col = cq * 4, rl = threadIdx.x >> 4;
+    float wq[4][3], bq[4], mu[4], rs[4], gr[4], a1[4], a2[4], ga[4], be[4], acc[4][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        wq[e][0] = W1[(col + e) * 3];
+        wq[e][1] = W1[(col + e) * 3 + 1];
+        wq[e][2] = W1[(col + e) * 3 + 2];
+        bq[e] = b1[col + e];
+        mu[e] = mean[col + e];
+        rs[e] = rstd[col + e];
+        ga[e] = gamma[col + e];
+        be[e] = beta[col + e];
+        gr[e] = ga[e] * rs[e];
+        a1[e] = m1[col + e];
+        a2[e] = m2[col + e];
+        acc[e][0] = acc[e][1] = acc[e][2] = 0.f;
+    }
+    const int r0 = blockIdx.x * 256;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        const int r = r0 + rl + 16 * j;
+        const bool ok = r < M;                      // uniform over the 16 lanes that share a row
+        const int rr = ok ? r : M - 1;
+        const float x0 = X3[(size_t)rr * 3], x1 = X3[(size_t)rr * 3 + 1], x2 = X3[(size_t)rr * 3 + 2];
+        const float4 gv = *(const float4*)(dh + (size_t)rr * 64 + col);
+        const float gin[4] = {gv.x, gv.y, gv.z, gv.w};
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y = conv1_pre(wq[e][0], wq[e][1], wq[e][2], bq[e], x0, x1, x2);
+            const float g = bn_pre(y, mu[e], rs[e], ga[e], be[e]) > 0.f ? gin[e] : 0.f;
+            const float o = ok ? gr[e] * (g - a1[e] - (y - mu[e]) * rs[e] * a2[e]) : 0.f;
+            acc[e][0] += o * x0;
+            acc[e][1] += o * x1;
+            acc[e][2] += o * x2;
+            d0 += o * wq[e][0];
+            d1 += o * wq[e][1];
+            d2 += o * wq[e][2];
+        }
+        if (dX3 != nullptr) {
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                d0 += __shfl_xor(d0, off);
+                d1 += __shfl_xor(d1, off);
+                d2 += __shfl_xor(d2, off);
+            }
+            if (cq == 0 && ok) {
+                dX3[(size_t)r * 3 + 0] = d0;
+                dX3[(size_t)r * 3 + 1] = d1;
+                dX3[(size_t)r * 3 + 2] = d2;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sw[rl][col + e][j] = acc[e][j];
+    __syncthreads();
+    if (threadIdx.x < 192) {
+        const int c = threadIdx.x / 3, j = threadIdx.x - 3 * c;
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += (double)sw[k][c][j];      // fixed order: reproducible
+        part[(size_t)blockIdx.x * 192 + threadIdx.x] = t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // exact-f32 MFMA GEMMs for the backward pass
 // ---------------------------------------------------------------------------------------------
@@ -952,6 +1029,35 @@ hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean
     else
         hipLaunchKernelGGL(k_bn_bwd_dense, grid1((size_t)M * C / 4), dim3(256), 0, s, dh, h, y, mean, rstd, gamma, m1, m2,
                            (size_t)M * C / 4, C, beta);
+    return hipGetLastError();
+}
+// the first half of t_bn_bwd for a per-point layer behind a ReLU: column sums of the masked gradient (mask from the
+// recomputed pre-activation) and what follows from them (m1, m2, dgamma, dbeta); dh is left as it is
+hipError_t t_bn_bwd_sums(const float* dh, const float* y, const float* mean, const float* rstd, const float* gamma,
+                         const float* beta, int M, int C, double* part, float* m1, float* m2, float* dgamma,
+                         float* dbeta, float* dbias_zero, hipStream_t s) {
+    if (!beta || C % 4 != 0) return hipErrorInvalidValue;
+    const int nblk = t_colreduce_blocks(M);
+    hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, dh, (const float*)nullptr, y, mean,
+                       rstd, M, C, 1, t_colreduce_rows(M), part, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, gamma, beta);
+    hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta,
+                       dbias_zero);
+    return hipGetLastError();
+}
+// the second half of t_bn_bwd for conv1's BatchNorm with the column sums already in part ([nblk][2][64] doubles),
+// followed by t_conv1_bwd, without storing dy1: dW1 and (dX3 != nullptr) dX3.  part is reused for the partial sums
+// of dW1 and must hold t_red_blocks(M) * 192 doubles.
+hipError_t t_conv1_bwd_from_sums(const float* dh1, const float* X3, const float* W1, const float* b1, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, int M, double* part, int nblk,
+                                 float* m1, float* m2, float* dgamma, float* dbeta, float* dbias_zero, float* dW1,
+                                 float* dX3, hipStream_t s) {
+    hipLaunchKernelGGL(k_bnbwd_finalize, grid1(64, FIN_COLS), dim3(256), 0, s, (const double*)part, nblk, M, 64, m1, m2,
+                       dgamma, dbeta, dbias_zero);
+    const int wblk = t_red_blocks(M);
+    hipLaunchKernelGGL(k_conv1_bwd_all, dim3(wblk), dim3(256), 0, s, dh1, X3, W1, b1, mean, rstd, gamma, beta,
+                       (const float*)m1, (const float*)m2, M, part, dX3);
+    hipLaunchKernelGGL(k_reduce_double, grid1(192, FIN_COLS), dim3(256), 0, s, (const double*)part, wblk, 192, dW1);
     return hipGetLastError();
 }
 hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s,

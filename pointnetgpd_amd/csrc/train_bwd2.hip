@@ -1,0 +1,230 @@
+// Backward of the second per-point layer of a stack in one pass over its rows (training step):
+//
+//     dy2 = gamma2 rstd2 (g - m1 - yhat m2),  g = dh2 masked by the ReLU behind BatchNorm 2,  yhat = (y2 - mean2) rstd2
+//     dh1 = dy2 W2                                                   ([M,128] x [128,64], exact f32 on the matrix pipe)
+//     s1[c] = sum_m g1[m,c],  s2[c] = sum_m g1[m,c] yhat1[m,c]       (column sums that BatchNorm 1's backward needs)
+//
+// (model/pointnet.py:30-31 / :143-146 run backwards: conv2 = a row-wise linear map, bn2 in training mode, relu.)
+// Done as three kernels this moves dh2 four times and y2 twice; here a lane reads its half row of dh2 and y2 once,
+// turns it into dy2 in registers, stores it (the weight-gradient product reads it next) and feeds the matrix pipe from
+// the same registers.  The product's accumulators are masked with the sign of conv1's recomputed pre-activation
+// (three fmas from the row's coordinates) and summed per column before dh1 is stored, so the column reduction over
+// dh1 needs no pass of its own.  Structure as tall_gemm_kernel<128,64>: persistent workgroups, W2 resident in LDS, the
+// next half tile (128 rows x 64 columns of dh2 and y2) in flight during the MFMAs.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "train_act.h"
+
+namespace pngpd {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace {
+constexpr int FK = 128, FN = 64, FNT = FN / 32;
+// W2 row k in LDS: every group of 32 rows starts 32 floats later than plain row-major, so the two rows an MFMA step
+// reads (k and k + 32, one per half wave) lie on different halves of the banks
+constexpr int F_W2_FLOATS = FK * FN + 32 * (FK / 32);
+__device__ __forceinline__ int w2_row_offset(int k) { return k * FN + 32 * (k >> 5); }
+constexpr int F_CONST = 7;      // per column of layer 2: mean, rstd, gamma, beta, m1, m2, gamma * rstd
+constexpr int F_CONST1 = 8;     // per column of layer 1: three weights, bias, mean, rstd, gamma, beta
+constexpr size_t F_LDS_BYTES = ((size_t)F_W2_FLOATS + F_CONST * FK + F_CONST1 * FN) * sizeof(float);
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void conv2_bwd_fused_kernel(
+    float* __restrict__ dh2, const float* __restrict__ y2, const float* __restrict__ mean2,
+    const float* __restrict__ rstd2, const float* __restrict__ gamma2, const float* __restrict__ beta2,
+    const float* __restrict__ m1, const float* __restrict__ m2, const float* __restrict__ W2, float* __restrict__ dh1,
+    int M, const float* __restrict__ X3, const float* __restrict__ W1, const float* __restrict__ b1,
+    const float* __restrict__ mean1, const float* __restrict__ rstd1, const float* __restrict__ gamma1,
+    const float* __restrict__ beta1, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float f_smem[];
+    float* sB = f_smem;
+    float* sC = f_smem + F_W2_FLOATS;      // [7][128]
+    float* sC1 = sC + F_CONST * FK;             // [8][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    for (int i = tid * 4; i < FK * FN; i += 1024) *(float4*)(sB + w2_row_offset(i / FN) + (i % FN)) = *(const float4*)(W2 + i);
+    if (tid < FK) {
+        const float mu = mean2[tid], rs = rstd2[tid], ga = gamma2[tid];
+        sC[0 * FK + tid] = mu;
+        sC[1 * FK + tid] = rs;
+        sC[2 * FK + tid] = ga;
+        sC[3 * FK + tid] = beta2[tid];
+        sC[4 * FK + tid] = m1[tid];
+        sC[5 * FK + tid] = m2[tid];
+        sC[6 * FK + tid] = ga * rs;
+    } else if (tid < FK + FN) {
+        const int c = tid - FK;
+        sC1[0 * FN + c] = W1[c * 3];
+        sC1[1 * FN + c] = W1[c * 3 + 1];
+        sC1[2 * FN + c] = W1[c * 3 + 2];
+        sC1[3 * FN + c] = b1[c];
+        sC1[4 * FN + c] = mean1[c];
+        sC1[5 * FN + c] = rstd1[c];
+        sC1[6 * FN + c] = gamma1[c];
+        sC1[7 * FN + c] = beta1[c];
+    }
+    __syncthreads();
+
+    double s1[FNT], s2[FNT];
+#pragma unroll
+    for (int t = 0; t < FNT; ++t) s1[t] = s2[t] = 0.0;
+
+    const int tiles = (M + 127) / 128;
+    // A tile of 128 rows is taken in two phases of 64 columns of dh2 (= 64 of the product's 128 summed terms): lane
+    // (r, h) owns the 32 consecutive floats [64p + 32h, 64p + 32h + 32) of its row in phase p, so MFMA step s of a
+    // phase pairs term 64p + s (lanes h = 0) with term 64p + 32 + s (lanes h = 1).  The next phase's floats of dh2
+    // and y2 are in flight while this phase's MFMAs run.
+    constexpr int PQ = 8;                          // float4 per lane and phase
+    float4 a[PQ], yv[PQ];
+    float xr[3];                                   // coordinates of this lane's row (layer-1 pre-activation of the epilogue)
+    auto load_phase = [&](int tile, int p) {
+        int row = tile * 128 + wave * 32 + r;
+        row = row < M ? row : M - 1;
+        const float4* sd = (const float4*)(dh2 + (size_t)row * FK + 64 * p + 32 * h);
+        const float4* sy = (const float4*)(y2 + (size_t)row * FK + 64 * p + 32 * h);
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            a[q] = sd[q];
+            yv[q] = sy[q];
+        }
+        if (p == 0) {
+            xr[0] = X3[(size_t)row * 3];
+            xr[1] = X3[(size_t)row * 3 + 1];
+            xr[2] = X3[(size_t)row * 3 + 2];
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < tiles) load_phase(tile, 0);
+    for (; tile < tiles; tile += gridDim.x) {
+        const int rowA = tile * 128 + wave * 32 + r;
+        const int next = tile + gridDim.x;
+        const float x0 = xr[0], x1 = xr[1], x2 = xr[2];
+        f32x16 acc[FNT];
+#pragma unroll
+        for (int t = 0; t < FNT; ++t) acc[t] = f32x16{0};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            // dy2 of this lane's 32 floats, in registers and (in place) in memory
+            float4 d[PQ];
+#pragma unroll
+            for (int q = 0; q < PQ; ++q) {
+                const float* cst = sC + 64 * p + 32 * h + 4 * q;
+                const float4 mu = *(const float4*)(cst), rs = *(const float4*)(cst + FK), ga = *(const float4*)(cst + 2 * FK),
+                             be = *(const float4*)(cst + 3 * FK), a1 = *(const float4*)(cst + 4 * FK),
+                             a2 = *(const float4*)(cst + 5 * FK), gr = *(const float4*)(cst + 6 * FK);
+                float4 g = a[q];
+                const float4 y = yv[q];
+                if (!(bn_pre(y.x, mu.x, rs.x, ga.x, be.x) > 0.f)) g.x = 0.f;
+                if (!(bn_pre(y.y, mu.y, rs.y, ga.y, be.y) > 0.f)) g.y = 0.f;
+                if (!(bn_pre(y.z, mu.z, rs.z, ga.z, be.z) > 0.f)) g.z = 0.f;
+                if (!(bn_pre(y.w, mu.w, rs.w, ga.w, be.w) > 0.f)) g.w = 0.f;
+                d[q].x = gr.x * (g.x - a1.x - (y.x - mu.x) * rs.x * a2.x);
+                d[q].y = gr.y * (g.y - a1.y - (y.y - mu.y) * rs.y * a2.y);
+                d[q].z = gr.z * (g.z - a1.z - (y.z - mu.z) * rs.z * a2.z);
+                d[q].w = gr.w * (g.w - a1.w - (y.w - mu.w) * rs.w * a2.w);
+            }
+            if (rowA < M) {
+                float4* dst = (float4*)(dh2 + (size_t)rowA * FK + 64 * p + 32 * h);
+#pragma unroll
+                for (int q = 0; q < PQ; ++q) dst[q] = d[q];
+            }
+            if (p == 0)
+                load_phase(tile, 1);
+            else if (next < tiles)
+                load_phase(next, 0);
+#pragma unroll
+            for (int q = 0; q < PQ; ++q) {
+                const float av[4] = {d[q].x, d[q].y, d[q].z, d[q].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* brow = sB + w2_row_offset(64 * p + 32 * h + 4 * q + e) + r;
+#pragma unroll
+                    for (int t = 0; t < FNT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], brow[32 * t], acc[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // accumulator i of a lane: row (i&3) + 8(i>>2) + 4h of the wave's 32 rows, column 32t + r
+        const int row0 = tile * 128 + wave * 32;
+        float f1[FNT], f2[FNT], w1[FNT][3], bb1[FNT], mu1[FNT], rs1[FNT], ga1[FNT], be1[FNT];
+        int c1off = r;
+        asm volatile("" : "+v"(c1off));            // read per tile: these sixteen values are not kept across the MFMAs
+#pragma unroll
+        for (int t = 0; t < FNT; ++t) {
+            const float* c1 = sC1 + c1off + 32 * t;
+            f1[t] = f2[t] = 0.f;
+            w1[t][0] = c1[0];
+            w1[t][1] = c1[FN];
+            w1[t][2] = c1[2 * FN];
+            bb1[t] = c1[3 * FN];
+            mu1[t] = c1[4 * FN];
+            rs1[t] = c1[5 * FN];
+            ga1[t] = c1[6 * FN];
+            be1[t] = c1[7 * FN];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int lr = (i & 3) + 8 * (i >> 2) + 4 * h;          // the lane that holds this row's coordinates
+            const float c0 = __shfl(x0, lr), c1 = __shfl(x1, lr), c2 = __shfl(x2, lr);
+            const int row = row0 + lr;
+            if (row < M) {
+#pragma unroll
+                for (int t = 0; t < FNT; ++t) {
+                    const float v = acc[t][i];
+                    const float y = conv1_pre(w1[t][0], w1[t][1], w1[t][2], bb1[t], c0, c1, c2);
+                    const float g = bn_pre(y, mu1[t], rs1[t], ga1[t], be1[t]) > 0.f ? v : 0.f;
+                    f1[t] += g;
+                    f2[t] += g * ((y - mu1[t]) * rs1[t]);
+                    dh1[(size_t)row * FN + 32 * t + r] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < FNT; ++t) {
+            s1[t] += (double)f1[t];
+            s2[t] += (double)f2[t];
+        }
+    }
+
+    // per lane -> per workgroup: 8 lane sums per column (4 waves x 2 halves), added in a fixed order
+    __syncthreads();
+    double* red = (double*)f_smem;                  // [8][64][2]
+#pragma unroll
+    for (int t = 0; t < FNT; ++t) {
+        double* p = red + ((size_t)(wave * 2 + h) * FN + 32 * t + r) * 2;
+        p[0] = s1[t];
+        p[1] = s2[t];
+    }
+    __syncthreads();
+    if (tid < FN) {
+        double u = 0.0, v = 0.0;
+        for (int k = 0; k < 8; ++k) {
+            u += red[((size_t)k * FN + tid) * 2];
+            v += red[((size_t)k * FN + tid) * 2 + 1];
+        }
+        part[((size_t)blockIdx.x * 2 + 0) * FN + tid] = u;
+        part[((size_t)blockIdx.x * 2 + 1) * FN + tid] = v;
+    }
+}
+
+// dh2 [M,128]: in dL/dh2 (before the ReLU mask), out dL/dy2.  dh1 [M,64]: dL/dh1 (before conv1's ReLU mask).
+// part: [tall_gemm_blocks(M)][2][64] doubles, the partial column sums for BatchNorm 1's backward.
+hipError_t launch_conv2_bwd_fused(float* dh2, const float* y2, const float* mean2, const float* rstd2,
+                                  const float* gamma2, const float* beta2, const float* m1, const float* m2,
+                                  const float* W2, float* dh1, int M, const float* X3, const float* W1, const float* b1,
+                                  const float* mean1, const float* rstd1, const float* gamma1, const float* beta1,
+                                  double* part, hipStream_t s) {
+    if (!dh2 || !y2 || !W2 || !dh1 || !X3 || !part || M < 1) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void*)conv2_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)F_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv2_bwd_fused_kernel, dim3(tall_gemm_blocks(M)), dim3(256), F_LDS_BYTES, s, dh2, y2, mean2, rstd2,
+                       gamma2, beta2, m1, m2, W2, dh1, M, X3, W1, b1, mean1, rstd1, gamma1, beta1, part);
+    return hipGetLastError();
+}
+
+}  // namespace pngpd
