@@ -156,33 +156,32 @@ __global__ __launch_bounds__(256, 2) void tall_gemm_kernel(const float* __restri
 
 // Batch statistics from the per-workgroup records (count, mean, M2): N = sum n_b, mean = sum n_b mean_b / N,
 // M2 = sum [M2_b + n_b (mean_b - mean)^2].  block = 4 columns x 64 record lanes; a lane sums every 64th record,
-// the 64 lane sums are added in a fixed order.  Same outputs as the two-pass statistics: mean, rstd (biased
-// variance, eps 1e-5) and the running update (momentum, unbiased variance).
+// the 64 lane sums are added in a fixed order (butterfly inside a wave, then the wave totals).  Same outputs as the
+// two-pass statistics: mean, rstd (biased variance, eps 1e-5) and the running update (momentum, unbiased variance).
 __global__ __launch_bounds__(256) void k_stats_from_records(const double* __restrict__ rec, int nrec, int M, int C,
                                                             float momentum, float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out,
                                                             float* __restrict__ running_mean,
                                                             float* __restrict__ running_var) {
     constexpr int COLS = 4, LANES = 64;
-    __shared__ double sh[LANES][COLS];
-    __shared__ double s_mean[COLS];
+    __shared__ double sh[2][4][COLS];
     const int cl = threadIdx.x & (COLS - 1), rl = threadIdx.x / COLS;
     const int c = blockIdx.x * COLS + cl;
+    // the 64 lane sums of a column: a butterfly over the 16 row lanes a wave holds, then the four wave totals
+    auto lane_sum = [&](double v, double (*buf)[COLS]) {
+#pragma unroll
+        for (int off = COLS; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) < COLS) buf[threadIdx.x >> 6][cl] = v;
+        __syncthreads();
+        return ((buf[0][cl] + buf[1][cl]) + buf[2][cl]) + buf[3][cl];
+    };
     double a = 0.0;
     if (c < C)
         for (int i = rl; i < nrec; i += LANES) {
             const double* p = rec + ((size_t)i * C + c) * 3;
             a += p[0] * p[1];
         }
-    sh[rl][cl] = a;
-    __syncthreads();
-    if (rl == 0) {
-        double t = 0.0;
-        for (int k = 0; k < LANES; ++k) t += sh[k][cl];
-        s_mean[cl] = t / M;
-    }
-    __syncthreads();
-    const double mean = s_mean[cl];
+    const double mean = lane_sum(a, sh[0]) / M;
     a = 0.0;
     if (c < C)
         for (int i = rl; i < nrec; i += LANES) {
@@ -190,12 +189,8 @@ __global__ __launch_bounds__(256) void k_stats_from_records(const double* __rest
             const double d = p[1] - mean;
             a += p[2] + p[0] * d * d;
         }
-    __syncthreads();
-    sh[rl][cl] = a;
-    __syncthreads();
+    const double m2 = lane_sum(a, sh[1]);
     if (rl != 0 || c >= C) return;
-    double m2 = 0.0;
-    for (int k = 0; k < LANES; ++k) m2 += sh[k][cl];
     double var = m2 / M;
     if (var < 0.0) var = 0.0;
     mean_out[c] = (float)mean;

@@ -241,10 +241,21 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ A, 
 // lane sums every 64th partial, the 64 lane sums are then added in a fixed order (reproducible).
 constexpr int FIN_COLS = 4, FIN_LANES = 64;
 
+// v summed over the 64 row lanes of a column (thread = row lane * FIN_COLS + column): a butterfly over the 16 row
+// lanes a wave holds, then the four wave totals in a fixed order.  The result is valid in row lane 0.
+__device__ __forceinline__ double fin_row_lane_sum(double v, double (*sh)[FIN_COLS]) {
+#pragma unroll
+    for (int off = FIN_COLS; off < 64; off <<= 1) v += __shfl_xor(v, off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < FIN_COLS) sh[wave][lane] = v;
+    __syncthreads();
+    const int cl = threadIdx.x & (FIN_COLS - 1);
+    return ((sh[0][cl] + sh[1][cl]) + sh[2][cl]) + sh[3][cl];
+}
+
 __device__ __forceinline__ void sum_partials2(const double* __restrict__ part, int nblk, int C, int c, int rl,
                                               double& s1, double& s2) {
-    __shared__ double sh[2][FIN_LANES][FIN_COLS];
-    const int cl = threadIdx.x & (FIN_COLS - 1);
+    __shared__ double sh[2][4][FIN_COLS];
     double a = 0.0, b = 0.0;
     if (c < C)
 #pragma unroll 4
@@ -252,16 +263,8 @@ __device__ __forceinline__ void sum_partials2(const double* __restrict__ part, i
             a += part[((size_t)i * 2 + 0) * C + c];
             b += part[((size_t)i * 2 + 1) * C + c];
         }
-    sh[0][rl][cl] = a;
-    sh[1][rl][cl] = b;
-    __syncthreads();
-    s1 = 0.0;
-    s2 = 0.0;
-    if (rl == 0)
-        for (int k = 0; k < FIN_LANES; ++k) {
-            s1 += sh[0][k][cl];
-            s2 += sh[1][k][cl];
-        }
+    s1 = fin_row_lane_sum(a, sh[0]);
+    s2 = fin_row_lane_sum(b, sh[1]);
 }
 
 // Finalise batch statistics: mean, rstd; update running stats (momentum, unbiased variance).
@@ -746,17 +749,14 @@ __global__ __launch_bounds__(256) void k_conv1_wgrad(const float* __restrict__ d
 
 __global__ __launch_bounds__(256) void k_reduce_double(const double* __restrict__ part, int nblk, int n,
                                                        float* __restrict__ out) {
-    __shared__ double sh[FIN_LANES][FIN_COLS];
+    __shared__ double sh[4][FIN_COLS];
     const int cl = threadIdx.x & (FIN_COLS - 1), rl = threadIdx.x / FIN_COLS;
     const int i = blockIdx.x * FIN_COLS + cl;
     double s = 0.0;
     if (i < n)
         for (int b = rl; b < nblk; b += FIN_LANES) s += part[(size_t)b * n + i];
-    sh[rl][cl] = s;
-    __syncthreads();
+    s = fin_row_lane_sum(s, sh);
     if (rl != 0 || i >= n) return;
-    s = 0.0;
-    for (int k = 0; k < FIN_LANES; ++k) s += sh[k][cl];
     out[i] = (float)s;
 }
 

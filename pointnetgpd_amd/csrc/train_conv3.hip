@@ -364,25 +364,35 @@ __global__ __launch_bounds__(256) void k_gram_mean(const double* __restrict__ co
     abar_d[i] = s / M;
 }
 
-// cov[i][j] = sum_chunks S_chunk[i][j] / M - abar_i abar_j.  block = 16 elements x 16 chunk lanes: a lane sums every
-// 16th chunk, the lane sums are added in a fixed order.
+// cov[i][j] = sum_chunks S_chunk[i][j] / M - abar_i abar_j.  `present` bit 4 (i / 32) + j / 32: that 32x32 block of the
+// partials was computed (the others are transposes of computed ones).  grid (32 rows, computed blocks): a workgroup
+// owns one row of one computed block - 32 consecutive doubles of every partial - as 32 elements x 8 chunk lanes; a
+// lane sums every 8th chunk, the lane sums are added in a fixed order, and the result goes to cov[i][j] and, for a
+// block off the diagonal whose mirror was not computed, to cov[j][i] as well.
 __global__ __launch_bounds__(256) void k_gram_finalize(const double* __restrict__ part, int chunks,
                                                        const double* __restrict__ abar_d, int M,
                                                        double* __restrict__ cov, unsigned present) {
-    __shared__ double sh[16][16];
-    const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int idx = blockIdx.x * 16 + el;
-    const int i = idx / C2, j = idx - i * C2;
-    // `present` bit 4 (i / 32) + j / 32: that 32x32 block was computed; the others are transposes of computed ones
-    const int src = (present >> (4 * (i >> 5) + (j >> 5))) & 1u ? idx : j * C2 + i;
+    __shared__ double sh[8][32];
+    const int el = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    // the blockIdx.y-th set bit of `present`
+    int blk = 0;
+    for (int seen = -1; blk < 16; ++blk)
+        if ((present >> blk) & 1u)
+            if (++seen == (int)blockIdx.y) break;
+    const int bi = blk >> 2, bj = blk & 3;
+    const int i = 32 * bi + (int)blockIdx.x, j = 32 * bj + el;
+    const size_t src = (size_t)i * C2 + j;
     double s = 0.0;
-    for (int c = rl; c < chunks; c += 16) s += part[(size_t)c * C2 * C2 + src];
+#pragma unroll 8
+    for (int c = rl; c < chunks; c += 8) s += part[(size_t)c * C2 * C2 + src];
     sh[rl][el] = s;
     __syncthreads();
     if (rl != 0) return;
     s = 0.0;
-    for (int k = 0; k < 16; ++k) s += sh[k][el];
-    cov[idx] = s / M - abar_d[i] * abar_d[j];
+    for (int k = 0; k < 8; ++k) s += sh[k][el];
+    const double v = s / M - abar_d[i] * abar_d[j];
+    cov[(size_t)i * C2 + j] = v;
+    if (bi != bj && !((present >> (4 * bj + bi)) & 1u)) cov[(size_t)j * C2 + i] = v;
 }
 
 // Index of W3[c][k] in the packed image the product/max kernel streams (32x32x2 fragments, same element
@@ -417,8 +427,9 @@ __device__ __forceinline__ float pow2_scale_to_2p13(float m) {
     return __builtin_bit_cast(float, (unsigned int)(127 + sx) << 23);
 }
 
-// one block of 128 threads per channel
-__global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restrict__ W3, const float* __restrict__ b3,
+// one block per channel: 128 columns x 4 groups of 32 rows of Cov for the product Cov w (one batch of loads per thread),
+// the first 128 threads do the rest
+__global__ __launch_bounds__(512) void k_conv3_stats_pack(const float* __restrict__ W3, const float* __restrict__ b3,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const double* __restrict__ cov,
@@ -428,24 +439,40 @@ __global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restric
                                                           float* __restrict__ running_var, float* __restrict__ w3p,
                                                           unsigned short* __restrict__ w3s,
                                                           float* __restrict__ sh, float* __restrict__ wsc) {
-    __shared__ double s_w[C2], s_q[C2], s_m[C2];
+    __shared__ double s_w[C2], s_q[2], s_m[2], s_t[3][C2];
     __shared__ float s_sc;
     __shared__ float s_max[2];
-    const int c = blockIdx.x, i = threadIdx.x;
+    const int c = blockIdx.x, i = threadIdx.x & (C2 - 1), jg = threadIdx.x >> 7;
     const float wf = W3[(size_t)c * C2 + i];
-    s_w[i] = (double)wf;
+    if (jg == 0) s_w[i] = (double)wf;
     __syncthreads();
     double t = 0.0;
-    for (int j = 0; j < C2; ++j) t += cov[(size_t)j * C2 + i] * s_w[j];    // Cov is symmetric: coalesced over i
-    s_q[i] = t * (double)wf;
-    s_m[i] = abar_d[i] * (double)wf;
+#pragma unroll
+    for (int j = 32 * jg; j < 32 * jg + 32; ++j) t += cov[(size_t)j * C2 + i] * s_w[j];    // Cov is symmetric: coalesced over i
+    if (jg != 0) s_t[jg - 1][i] = t;
     __syncthreads();
-    if (i == 0) {
-        double var = 0.0, wa = 0.0;
-        for (int j = 0; j < C2; ++j) {
-            var += s_q[j];
-            wa += s_m[j];
-        }
+    const bool lead = jg == 0;                   // the first 128 threads do the rest; the others only keep the barriers
+    // var = sum_i w_i (Cov w)_i and wa = sum_i abar_i w_i: butterfly sums inside each of the two leading waves (every
+    // lane ends with the same total), then the two wave totals in a fixed order
+    double vq = 0.0, vm = 0.0;
+    if (lead) {
+        t = ((t + s_t[0][i]) + s_t[1][i]) + s_t[2][i];
+        vq = t * (double)wf;
+        vm = abar_d[i] * (double)wf;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        vq += __shfl_xor(vq, off);
+        vm += __shfl_xor(vm, off);
+    }
+    if (lead && (i & 63) == 0) {
+        s_q[i >> 6] = vq;
+        s_m[i >> 6] = vm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double var = s_q[0] + s_q[1];
+        const double wa = s_m[0] + s_m[1];
         if (var < 0.0) var = 0.0;
         const double mu = wa + (double)b3[c];
         const double rs = 1.0 / sqrt(var + (double)BN_EPS3);
@@ -462,7 +489,7 @@ __global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restric
     }
     __syncthreads();
     const float wv = wf * s_sc;
-    w3p[w3p_index(c, i)] = wv;
+    if (lead) w3p[w3p_index(c, i)] = wv;
     if (w3s != nullptr && wsc != nullptr) {
         // The same weight as TWO float16 pieces (conv3_pool_train_ws_kernel): the channel's row is first scaled by a
         // power of two that puts its largest entry in [2^13, 2^14) - float16 has 11 significand bits but only 5
@@ -470,8 +497,9 @@ __global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restric
         float m = fabsf(wv);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        if ((i & 63) == 0) s_max[i >> 6] = m;
+        if (lead && (i & 63) == 0) s_max[i >> 6] = m;
         __syncthreads();
+        if (!lead) return;
         m = fmaxf(s_max[0], s_max[1]);
         const float up = pow2_scale_to_2p13(m);
         if (i == 0) wsc[c] = 1.0f / up;                       // a power of two: exact
@@ -481,7 +509,7 @@ __global__ __launch_bounds__(128) void k_conv3_stats_pack(const float* __restric
         const int base = w3h16_index(c, i);
         w3s[base] = __builtin_bit_cast(unsigned short, hi);
         w3s[base + 512] = __builtin_bit_cast(unsigned short, lo);
-    } else if (w3s != nullptr) {
+    } else if (w3s != nullptr && lead) {
         // the same weight as three bfloat16 pieces (wv = hi + mid + lo to 2^-27), in 32x32x16 fragment order
         const __bf16 hi = (__bf16)wv;
         const float r1 = wv - (float)hi;
@@ -1327,15 +1355,16 @@ hipError_t t_conv3_fwd(float* h2, const float* W3, const float* b3, const float*
                            gram_part, colsum, gram_mean, bn2_rstd, bn2_gamma, bn2_beta, h2);
     hipLaunchKernelGGL(k_gram_mean, dim3(C2 / 16), dim3(256), 0, s, (const double*)colsum, chunks, M, w.abar_d);
     // 32x32 blocks of a partial that its kernel wrote (bit 4 i + j)
-    hipLaunchKernelGGL(k_gram_finalize, dim3(C2 * C2 / 16), dim3(256), 0, s, (const double*)gram_part, chunks,
-                       (const double*)w.abar_d, M, w.cov, gram_f64 ? 0xCCFFu : 0xAC6Fu);
+    const unsigned present = gram_f64 ? 0xCCFFu : 0xAC6Fu;
+    hipLaunchKernelGGL(k_gram_finalize, dim3(32, __builtin_popcount(present)), dim3(256), 0, s, (const double*)gram_part,
+                       chunks, (const double*)w.abar_d, M, w.cov, present);
     // PNGPD_TRAIN_CONV3 selects the product/max kernel: f32 (v_mfma_f32_32x32x2_f32), x6 (six products of bfloat16 pieces),
     // default: three products of float16 pieces with the weights stationary in registers; read at every call, like
     // PNGPD_TRAIN_GRAM above
     const char* conv3_env = getenv("PNGPD_TRAIN_CONV3");
     const bool use_f32 = (conv3_env && conv3_env[0] == 'f') || w.w3s == nullptr;
     const bool use_x6 = !use_f32 && ((conv3_env && conv3_env[0] == 'x') || w.wsc == nullptr);
-    hipLaunchKernelGGL(k_conv3_stats_pack, dim3(C3), dim3(128), 0, s, W3, b3, gamma, beta, (const double*)w.cov,
+    hipLaunchKernelGGL(k_conv3_stats_pack, dim3(C3), dim3(512), 0, s, W3, b3, gamma, beta, (const double*)w.cov,
                        (const double*)w.abar_d, M, momentum, mean, rstd, running_mean, running_var, w.w3p, w.w3s, w.sh,
                        use_x6 ? (float*)nullptr : w.wsc);
     // enough workgroups for two per CU: split the channels of a candidate when the batch is small
