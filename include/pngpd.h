@@ -102,6 +102,17 @@ int pngpd_model_destroy(pngpd_model* m);
  */
 int pngpd_model_load(pngpd_model* m, const float* const* host_tensors, int n_slots, void* stream);
 
+/*
+ * The same for parameters that already live in device memory (a network that was just trained on this GPU;
+ * model.eval() after the training loop of main_1v.py:262-274): device_tensors is a HOST array of PNGPD_SLOTS
+ * DEVICE pointers laid out like the table above.  Folding and the fragment images are computed by kernels queued on
+ * `stream` - the same float64 operations in the same order as pngpd_model_load, so both loaders give bit-identical
+ * models - and the call returns without waiting: the tensors must stay valid and unchanged until the stream has
+ * passed this point.  Every pointer is looked up before anything is launched (a device allocation on the model's
+ * GPU that holds the tensor's extent, else PNGPD_ERR_INVALID).
+ */
+int pngpd_model_load_device(pngpd_model* m, const float* const* device_tensors, int n_slots, void* stream);
+
 /* Bytes of device workspace pngpd_forward_infer() needs for a batch of B candidates. */
 size_t pngpd_forward_workspace_bytes(const pngpd_model* m, int B);
 

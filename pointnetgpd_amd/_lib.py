@@ -37,6 +37,7 @@ SIGNATURES = {
     "pngpd_model_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int]),
     "pngpd_model_destroy": (c_int, [c_void_p]),
     "pngpd_model_load": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p]),
+    "pngpd_model_load_device": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p]),
     "pngpd_forward_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "pngpd_forward_infer": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -22,6 +22,7 @@ ARCH = "gfx950"
 LIB_SOURCES = [
     "api.cpp",
     "pack.cpp",
+    "pack_device.hip",
     "launch_util.cpp",
     "conv_stack.hip",
     "conv_stack_x3.hip",

@@ -11,6 +11,7 @@
 #include "api_common.h"
 #include "kernels.h"
 #include "pack.h"
+#include "pack_device.h"
 #include "pngpd.h"
 
 namespace {
@@ -51,6 +52,20 @@ struct DevBuf {
             bytes = n;
         }
         return hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, s);
+    }
+    // the allocation alone (a kernel fills it)
+    hipError_t reserve(size_t n) {
+        if (p && n != bytes) {
+            (void)hipFree(p);
+            p = nullptr;
+            bytes = 0;
+        }
+        if (!p) {
+            hipError_t e = hipMalloc(&p, n);
+            if (e != hipSuccess) return e;
+            bytes = n;
+        }
+        return hipSuccess;
     }
 };
 
@@ -346,6 +361,137 @@ int pngpd_model_load(pngpd_model* m, const float* const* host_tensors, int n_slo
     if (m->parts & PNGPD_PART_HEAD)
         if ((rc = load_fc(host_tensors, PNGPD_U_FC1, m->k, m->head_fc, keep_fc, keep16, s))) return rc;
     HIP_TRY(hipStreamSynchronize(s));   // staging vectors die at return
+    m->loaded = true;
+    return PNGPD_OK;
+}
+
+namespace {
+
+// `n` floats readable at device pointer `p` on the current device?  A host pointer handed to a kernel would fault
+// the GPU, so every tensor of a device table is looked up before anything is launched.
+int check_device_tensor(const float* p, size_t n, int dev, int unit, int field) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(PNGPD_ERR_INVALID, "weight table: unit %d field %d is not a device pointer", unit, field);
+    }
+    if (at.type != hipMemoryTypeDevice || at.device != dev)
+        return fail(PNGPD_ERR_INVALID, "weight table: unit %d field %d does not live on device %d", unit, field, dev);
+    hipDeviceptr_t base = nullptr;
+    size_t extent = 0;
+    if (hipMemGetAddressRange(&base, &extent, (hipDeviceptr_t)p) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(PNGPD_ERR_INVALID, "weight table: unit %d field %d has no allocation behind it", unit, field);
+    }
+    const size_t off = (size_t)((const char*)p - (const char*)base);
+    if (off + n * sizeof(float) > extent)
+        return fail(PNGPD_ERR_INVALID, "weight table: unit %d field %d: %zu floats do not fit its allocation", unit, field,
+                    n);
+    if (((uintptr_t)p & 3u) != 0)
+        return fail(PNGPD_ERR_INVALID, "weight table: unit %d field %d is not aligned to 4 bytes", unit, field);
+    return PNGPD_OK;
+}
+
+pngpd::UnitDev unit_dev(const float* const* t, int u, bool has_bn) {
+    const float* const* f = t + u * PNGPD_FIELDS;
+    pngpd::UnitDev d;
+    d.W = f[PNGPD_F_WEIGHT];
+    d.b = f[PNGPD_F_BIAS];
+    d.gamma = has_bn ? f[PNGPD_F_BN_WEIGHT] : nullptr;
+    d.beta = has_bn ? f[PNGPD_F_BN_BIAS] : nullptr;
+    d.mean = has_bn ? f[PNGPD_F_BN_MEAN] : nullptr;
+    d.var = has_bn ? f[PNGPD_F_BN_VAR] : nullptr;
+    return d;
+}
+
+int load_stack_device(const float* const* t, int u_conv1, StackDev& d, hipStream_t s) {
+    using namespace pngpd;
+    HIP_TRY(d.w1tab.reserve((size_t)C1 * 4 * 4));
+    HIP_TRY(d.b2p.reserve((size_t)B2P_FLOATS * 4));
+    HIP_TRY(d.b2.reserve((size_t)C2 * 4));
+    HIP_TRY(d.b3.reserve((size_t)C3 * 4));
+    HIP_TRY(d.w2_bf16.reserve((size_t)C2 * C1 * 2));
+    HIP_TRY(d.w3_bf16.reserve((size_t)C3 * C2 * 2));
+    HIP_TRY(d.w2_lo.reserve((size_t)C2 * C1 * 2));
+    HIP_TRY(d.w3_lo.reserve((size_t)C3 * C2 * 2));
+    HIP_TRY(d.w2_f32.reserve((size_t)C2 * C1 * 4));
+    HIP_TRY(d.w3_f32.reserve((size_t)C3 * C2 * 4));
+    StackImages o;
+    o.w1tab = (float*)d.w1tab.p;
+    o.b2p = (float*)d.b2p.p;
+    o.b2 = (float*)d.b2.p;
+    o.b3 = (float*)d.b3.p;
+    o.w2_bf16 = (uint16_t*)d.w2_bf16.p;
+    o.w3_bf16 = (uint16_t*)d.w3_bf16.p;
+    o.w2_lo = (uint16_t*)d.w2_lo.p;
+    o.w3_lo = (uint16_t*)d.w3_lo.p;
+    o.w2_f32 = (float*)d.w2_f32.p;
+    o.w3_f32 = (float*)d.w3_f32.p;
+    HIP_TRY(launch_pack_stack_device(unit_dev(t, u_conv1, true), unit_dev(t, u_conv1 + 1, true),
+                                     unit_dev(t, u_conv1 + 2, true), o, s));
+    return PNGPD_OK;
+}
+
+int load_fc_device(const float* const* t, int u_fc1, int n_last, FcDev& d, hipStream_t s) {
+    const int n[3] = {512, 256, n_last}, k[3] = {1024, 512, 256};
+    for (int i = 0; i < 3; ++i) {
+        HIP_TRY(d.w[i].reserve((size_t)n[i] * k[i] * 4));
+        HIP_TRY(d.b[i].reserve((size_t)n[i] * 4));
+        if (i < 2) HIP_TRY(d.wsplit[i].reserve((size_t)n[i] * k[i] * 2 * 2));
+        HIP_TRY(pngpd::launch_pack_fc_device(unit_dev(t, u_fc1 + i, i < 2), n[i], k[i], (float*)d.w[i].p, (float*)d.b[i].p,
+                                             i < 2 ? (uint16_t*)d.wsplit[i].p : nullptr, s));
+        d.n[i] = n[i];
+        d.k[i] = k[i];
+    }
+    return PNGPD_OK;
+}
+
+// floats of field `field` of unit `u` (k = classes of the head)
+size_t unit_field_floats(int u, int field, int k) {
+    static const int n_out[PNGPD_UNITS] = {64, 128, 1024, 512, 256, 9, 64, 128, 1024, 512, 256, 0};
+    static const int n_in[PNGPD_UNITS] = {3, 64, 128, 1024, 512, 256, 3, 64, 128, 1024, 512, 256};
+    const size_t o = u == PNGPD_U_FC3 ? (size_t)k : (size_t)n_out[u];
+    return field == PNGPD_F_WEIGHT ? o * n_in[u] : o;
+}
+
+}  // namespace
+
+int pngpd_model_load_device(pngpd_model* m, const float* const* device_tensors, int n_slots, void* stream) {
+    if (!m || !device_tensors) return fail(PNGPD_ERR_INVALID, "pngpd_model_load_device: NULL argument");
+    if (n_slots != PNGPD_SLOTS)
+        return fail(PNGPD_ERR_INVALID, "weight table must have %d slots, got %d", PNGPD_SLOTS, n_slots);
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != m->device)
+        return fail(PNGPD_ERR_STATE, "model lives on device %d but device %d is current", m->device, dev);
+    // the whole table is validated before the first launch
+    for (int u = 0; u < PNGPD_UNITS; ++u) {
+        const bool owned = u <= PNGPD_U_STN_FC3 ? (m->parts & PNGPD_PART_STN)
+                           : u <= PNGPD_U_FEAT_CONV3 ? (m->parts & PNGPD_PART_TRUNK) : (m->parts & PNGPD_PART_HEAD);
+        if (!owned) continue;
+        const float* const* f = device_tensors + u * PNGPD_FIELDS;
+        const bool has_bn = (u != PNGPD_U_STN_FC3 && u != PNGPD_U_FC3);
+        if (!f[PNGPD_F_WEIGHT] || !f[PNGPD_F_BIAS])
+            return fail(PNGPD_ERR_INVALID, "weight table: unit %d has no weight/bias", u);
+        if (has_bn && (!f[PNGPD_F_BN_WEIGHT] || !f[PNGPD_F_BN_BIAS] || !f[PNGPD_F_BN_MEAN] || !f[PNGPD_F_BN_VAR]))
+            return fail(PNGPD_ERR_INVALID, "weight table: unit %d lacks BatchNorm tensors", u);
+        for (int field = 0; field < PNGPD_FIELDS; ++field) {
+            if (!f[field] || (!has_bn && field >= PNGPD_F_BN_WEIGHT)) continue;
+            const int rc = check_device_tensor(f[field], unit_field_floats(u, field, m->k), dev, u, field);
+            if (rc) return rc;
+        }
+    }
+    m->loaded = false;
+    int rc;
+    if (m->parts & PNGPD_PART_STN) {
+        if ((rc = load_stack_device(device_tensors, PNGPD_U_STN_CONV1, m->stn, s))) return rc;
+        if ((rc = load_fc_device(device_tensors, PNGPD_U_STN_FC1, 9, m->stn_fc, s))) return rc;
+    }
+    if (m->parts & PNGPD_PART_TRUNK)
+        if ((rc = load_stack_device(device_tensors, PNGPD_U_FEAT_CONV1, m->trunk, s))) return rc;
+    if (m->parts & PNGPD_PART_HEAD)
+        if ((rc = load_fc_device(device_tensors, PNGPD_U_FC1, m->k, m->head_fc, s))) return rc;
     m->loaded = true;
     return PNGPD_OK;
 }

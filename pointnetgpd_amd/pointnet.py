@@ -153,14 +153,24 @@ class _HipBacked(nn.Module):
                 if t is not None:
                     slots.append(ui * len(_lib.FIELDS) + fi)
                     parts.append(t.detach().to(torch.float32).reshape(-1))
-        # one device-to-host transfer for all tensors (68 separate ones cost a synchronisation each)
-        host = torch.cat(parts).cpu()
-        off = 0
-        for slot, part in zip(slots, parts):
-            table[slot] = host.data_ptr() + 4 * off
-            off += part.numel()
         with torch.cuda.device(h.device):
             stream = torch.cuda.current_stream(h.device).cuda_stream
+            if all(t.device == h.device for t in parts) and os.environ.get("PNGPD_HOST_FOLD", "0") != "1":
+                # the parameters already live on the GPU (a model that was just trained there, or moved with .cuda()):
+                # BatchNorm is folded and the images are built by kernels on the stream, nothing crosses to the host and
+                # nothing waits.  `parts` holds the (possibly converted) tensors until the call has queued its kernels;
+                # their memory is recycled in stream order.
+                parts = [t.contiguous() for t in parts]
+                for slot, part in zip(slots, parts):
+                    table[slot] = part.data_ptr()
+                _lib.check(h.lib.pngpd_model_load_device(h.ptr, table, _lib.SLOTS, ctypes.c_void_p(stream)))
+                return
+            # one device-to-host transfer for all tensors (68 separate ones cost a synchronisation each)
+            host = torch.cat(parts).cpu()
+            off = 0
+            for slot, part in zip(slots, parts):
+                table[slot] = host.data_ptr() + 4 * off
+                off += part.numel()
             _lib.check(h.lib.pngpd_model_load(h.ptr, table, _lib.SLOTS, ctypes.c_void_p(stream)))
 
     def _check_input(self, x: torch.Tensor, layout: int):

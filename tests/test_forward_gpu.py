@@ -354,3 +354,65 @@ def test_small_batches_cut_over_points_are_bitwise_equal_to_rows_of_a_large_batc
     g1, t1 = f(x[7:8].contiguous())
     assert torch.equal(g1, g64[7:8]) and torch.equal(t1, t64[7:8])
     assert torch.equal(g64, feat) and torch.equal(t64, trans)
+
+
+@pytest.mark.parametrize("k,seed", [(2, 41), (3, 42)])
+def test_weights_folded_on_the_device_give_the_model_folded_on_the_host_bit_for_bit(monkeypatch, k, seed):
+    """Parameters that already live on the GPU are folded and packed there (pngpd_model_load_device: no copy to the
+    host, no wait); PNGPD_HOST_FOLD=1 sends them through the host loader instead.  Same float64 operations in the same
+    order: log-probabilities, transform and global feature of the two models are equal bit for bit in all three
+    arithmetic modes, for the classifier and for the two stand-alone modules, also with a non-contiguous and a
+    half-precision parameter in the table."""
+    P, B = 750, 19
+    sd = synth.torch_state_dict(seed, k, 1.0, 2.0)
+    x = torch.from_numpy(synth.candidate_points(seed, B, P)).cuda()
+    outs = {}
+    for how in ("host", "device"):
+        if how == "host":
+            monkeypatch.setenv("PNGPD_HOST_FOLD", "1")
+        else:
+            monkeypatch.delenv("PNGPD_HOST_FOLD", raising=False)
+        m = PointNetCls(P, 3, k)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().eval()
+        stn, feat = STN3d(P, 3), PointNetfeat(P, 3)
+        stn.load_state_dict({n[len("feat.stn."):]: v for n, v in sd.items() if n.startswith("feat.stn.")})
+        feat.load_state_dict({n[len("feat."):]: v for n, v in sd.items() if n.startswith("feat.")})
+        stn, feat = stn.cuda().eval(), feat.cuda().eval()
+        # a non-contiguous weight (a transposed view of the transposed storage) and a half-precision BatchNorm scale
+        w = m.fc2.weight.data
+        m.fc2.weight.data = w.t().contiguous().t()
+        assert not m.fc2.weight.is_contiguous()
+        m.bn1.weight.data = m.bn1.weight.data.half()
+        got = []
+        for precision in ("fp32", "bf16x3", "bf16"):
+            for mod in (m, stn, feat):
+                mod.precision = precision
+            logp, trans = m(x)
+            got += [logp, trans, stn(x), feat(x)[0]]
+        torch.cuda.synchronize()
+        outs[how] = [t.cpu().numpy().copy() for t in got]
+    for a, b in zip(outs["host"], outs["device"]):
+        assert np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b)
+
+
+def test_device_weight_table_with_a_host_pointer_is_refused():
+    """A host address in the device table would fault the GPU inside a kernel: every pointer is looked up first."""
+    import ctypes
+    from pointnetgpd_amd import _lib
+    P, k = 64, 2
+    m = hip_model(P, k, 43, 1.0, "fp32")
+    m(torch.zeros(2, 3, P, device="cuda"))                      # creates the handle
+    h = m._handle(torch.device("cuda", torch.cuda.current_device()))
+    table = (ctypes.c_void_p * _lib.SLOTS)()
+    host = torch.zeros(1 << 20)
+    for i in range(_lib.SLOTS):
+        table[i] = host.data_ptr()
+    rc = h.lib.pngpd_model_load_device(h.ptr, table, _lib.SLOTS, None)
+    assert rc == 1, rc                                           # PNGPD_ERR_INVALID
+    assert b"device" in h.lib.pngpd_last_error()
+    # the refused call launched nothing and left the model as it was
+    logp, _ = m(torch.zeros(2, 3, P, device="cuda"))
+    torch.cuda.synchronize()
+    assert torch.isfinite(logp).all()
