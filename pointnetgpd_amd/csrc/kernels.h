@@ -210,6 +210,11 @@ hipError_t launch_conv2_bwd_fused(float* dh2, const float* y2, const float* mean
                                   const float* W2, float* dh1, int M, const float* X3, const float* W1, const float* b1,
                                   const float* mean1, const float* rstd1, const float* gamma1, const float* beta1,
                                   double* part, hipStream_t s);
+// forward of conv1 / bn1 / relu / conv2 in one pass (statistics of bn1 given): h1, y2 and the column-statistic records
+// of y2 ([tall_gemm_blocks(M)][128][3] doubles, for t_stats_from_records)
+hipError_t launch_conv12_fwd(const float* X3, const float* W1, const float* b1, const float* mean1, const float* rstd1,
+                             const float* gamma1, const float* beta1, const float* W2, const float* b2, float* h1,
+                             float* y2, int M, double* stat_rec, hipStream_t s);
 hipError_t t_conv1_bwd_from_sums(const float* dh1, const float* X3, const float* W1, const float* b1, const float* mean,
                                  const float* rstd, const float* gamma, const float* beta, int M, double* part, int nblk,
                                  float* m1, float* m2, float* dgamma, float* dbeta, float* dbias_zero, float* dW1,

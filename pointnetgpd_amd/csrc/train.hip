@@ -944,6 +944,7 @@ hipError_t t_conv1_bn_fwd(const float* X3, const float* W1, const float* b1, con
     hipLaunchKernelGGL(k_x3_moments, dim3(nblk), dim3(256), 0, s, X3, M, part);
     hipLaunchKernelGGL(k_conv1_stats, dim3(1), dim3(576), 0, s, (const double*)part, nblk, M, W1, b1, momentum, mean, rstd,
                        running_mean, running_var);
+    if (h1 == nullptr) return hipGetLastError();      // statistics only: the caller makes h1 where it is consumed
     int blocks = (M + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_conv1_bn_fwd, dim3(blocks), dim3(256), 0, s, X3, W1, b1, (const float*)mean, (const float*)rstd,

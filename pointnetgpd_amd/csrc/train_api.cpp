@@ -153,14 +153,23 @@ int fwd_stack(StackWs& S, float* const* p, int u1, const float* x, const float* 
               float momentum, double* part, double* gram_part, hipStream_t s) {
     const int M = B * P;
     HIP_TRY(pngpd::t_points_to_rows(x, trans, S.X3, B, P, s));
-    // conv1 + bn1 + relu: statistics from the moments of the points, one pass that writes h1
+    // bn1's statistics from the moments of the points; then conv1 + bn1 + relu + conv2 in one pass that writes h1 and
+    // y2 and takes the column statistics of y2 from the accumulators (PNGPD_TRAIN_FWD12=split: h1 by a pass of its own,
+    // conv2 as a tall product reading it).  relu(bn(conv2)) is applied by the first pass of the conv3 block (t_conv3_fwd)
+    const char* fwd12_env = getenv("PNGPD_TRAIN_FWD12");
+    const bool fwd12_split = fwd12_env && fwd12_env[0] == 's';
     HIP_TRY(pngpd::t_conv1_bn_fwd(S.X3, slot(p, u1, PNGPD_F_WEIGHT), slot(p, u1, PNGPD_F_BIAS),
                                   slot(p, u1, PNGPD_F_BN_WEIGHT), slot(p, u1, PNGPD_F_BN_BIAS), momentum, part, S.mean[0],
-                                  S.rstd[0], slot(p, u1, PNGPD_F_BN_MEAN), slot(p, u1, PNGPD_F_BN_VAR), S.h1, M, s));
-    // conv2 with the column statistics of its output taken from the accumulators; relu(bn(conv2)) is applied by
-    // the first pass of the conv3 block over these rows (t_conv3_fwd)
-    HIP_TRY(pngpd::launch_tall_gemm(S.h1, slot(p, u1 + 1, PNGPD_F_WEIGHT), 0, slot(p, u1 + 1, PNGPD_F_BIAS), S.y2, M, C2,
-                                    C1, 0, part, s));
+                                  S.rstd[0], slot(p, u1, PNGPD_F_BN_MEAN), slot(p, u1, PNGPD_F_BN_VAR),
+                                  fwd12_split ? S.h1 : nullptr, M, s));
+    if (fwd12_split)
+        HIP_TRY(pngpd::launch_tall_gemm(S.h1, slot(p, u1 + 1, PNGPD_F_WEIGHT), 0, slot(p, u1 + 1, PNGPD_F_BIAS), S.y2, M,
+                                        C2, C1, 0, part, s));
+    else
+        HIP_TRY(pngpd::launch_conv12_fwd(S.X3, slot(p, u1, PNGPD_F_WEIGHT), slot(p, u1, PNGPD_F_BIAS), S.mean[0], S.rstd[0],
+                                         slot(p, u1, PNGPD_F_BN_WEIGHT), slot(p, u1, PNGPD_F_BN_BIAS),
+                                         slot(p, u1 + 1, PNGPD_F_WEIGHT), slot(p, u1 + 1, PNGPD_F_BIAS), S.h1, S.y2, M,
+                                         part, s));
     HIP_TRY(pngpd::t_stats_from_records(part, pngpd::tall_gemm_blocks(M), M, C2, momentum, S.mean[1], S.rstd[1],
                                         slot(p, u1 + 1, PNGPD_F_BN_MEAN), slot(p, u1 + 1, PNGPD_F_BN_VAR), s));
     const int u3 = u1 + 2;

@@ -1,4 +1,7 @@
-// Backward of the second per-point layer of a stack in one pass over its rows (training step):
+// Fused passes over the per-point layers of a stack in the training step (conv12_fwd_kernel: forward of the first two
+// layers; conv2_bwd_fused_kernel: the backward of the second).
+//
+// Backward of the second per-point layer of a stack in one pass over its rows:
 //
 //     dy2 = gamma2 rstd2 (g - m1 - yhat m2),  g = dh2 masked by the ReLU behind BatchNorm 2,  yhat = (y2 - mean2) rstd2
 //     dh1 = dy2 W2                                                   ([M,128] x [128,64], exact f32 on the matrix pipe)
@@ -209,6 +212,178 @@ __global__ __launch_bounds__(256, 2) void conv2_bwd_fused_kernel(
         part[((size_t)blockIdx.x * 2 + 0) * FN + tid] = u;
         part[((size_t)blockIdx.x * 2 + 1) * FN + tid] = v;
     }
+}
+
+// Forward of the first two per-point layers in one pass: h1 = relu(bn1(W1 x + b1)) is computed from the three
+// coordinates of the row in the registers that feed the matrix pipe (and stored once, for the backward pass),
+// y2 = h1 W2^T + b2 comes out of the MFMAs together with the column statistics BatchNorm 2 needs (records of
+// count, mean, sum of squared deviations per workgroup, as tall_gemm_kernel writes them).
+// (model/pointnet.py:30-31 / :143-144: relu(bn1(conv1(x))), conv2.)
+// Lane (r, h) owns row r of the wave's 32 rows and the 32 channels [32h, 32h + 32) of h1: MFMA step s pairs term s
+// (lanes h = 0) with term 32 + s (lanes h = 1).
+namespace {
+constexpr int GK = 64, GN = 128, GNT = GN / 32;
+constexpr int G_W2_FLOATS = GK * GN + 32;          // rows k >= 32 start 32 floats later (other half of the banks)
+constexpr size_t G_LDS_BYTES = ((size_t)G_W2_FLOATS + F_CONST1 * GK) * sizeof(float);
+constexpr size_t G_RED_BYTES = (size_t)8 * GN * 3 * sizeof(double);
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void conv12_fwd_kernel(const float* __restrict__ X3, const float* __restrict__ W1,
+                                                            const float* __restrict__ b1, const float* __restrict__ mean1,
+                                                            const float* __restrict__ rstd1,
+                                                            const float* __restrict__ gamma1,
+                                                            const float* __restrict__ beta1, const float* __restrict__ W2,
+                                                            const float* __restrict__ b2, float* __restrict__ h1,
+                                                            float* __restrict__ y2, int M, double* __restrict__ stat_rec) {
+    extern __shared__ __attribute__((aligned(16))) float g_smem[];
+    float* sB = g_smem;                          // B[k][n] = W2[n][k]
+    float* sC1 = g_smem + G_W2_FLOATS;           // [8][64]: three weights, bias, mean, rstd, gamma, beta of layer 1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < GK * GN; i += 256) {
+        const int n = i / GK, k = i - n * GK;
+        sB[k * GN + n + (k >= GK / 2 ? 32 : 0)] = W2[i];
+    }
+    if (tid < GK) {
+        sC1[0 * GK + tid] = W1[tid * 3];
+        sC1[1 * GK + tid] = W1[tid * 3 + 1];
+        sC1[2 * GK + tid] = W1[tid * 3 + 2];
+        sC1[3 * GK + tid] = b1[tid];
+        sC1[4 * GK + tid] = mean1[tid];
+        sC1[5 * GK + tid] = rstd1[tid];
+        sC1[6 * GK + tid] = gamma1[tid];
+        sC1[7 * GK + tid] = beta1[tid];
+    }
+    __syncthreads();
+
+    float bv[GNT];
+#pragma unroll
+    for (int t = 0; t < GNT; ++t) bv[t] = b2[32 * t + r];
+    double cnt = 0.0, s1[GNT], s2[GNT];
+    float a0[GNT];
+#pragma unroll
+    for (int t = 0; t < GNT; ++t) {
+        s1[t] = 0.0;
+        s2[t] = 0.0;
+        a0[t] = 0.f;
+    }
+
+    const int tiles = (M + 127) / 128;
+    float xn[3];
+    auto load_point = [&](int tile) {
+        int row = tile * 128 + wave * 32 + r;
+        row = row < M ? row : M - 1;
+        xn[0] = X3[(size_t)row * 3];
+        xn[1] = X3[(size_t)row * 3 + 1];
+        xn[2] = X3[(size_t)row * 3 + 2];
+    };
+    int tile = blockIdx.x;
+    if (tile < tiles) load_point(tile);
+    for (; tile < tiles; tile += gridDim.x) {
+        const float x0 = xn[0], x1 = xn[1], x2 = xn[2];
+        const int next = tile + gridDim.x;
+        if (next < tiles) load_point(next);
+        const int rowA = tile * 128 + wave * 32 + r;
+        float4 a[GK / 8];
+#pragma unroll
+        for (int q = 0; q < GK / 8; ++q) {
+            const float* cst = sC1 + 32 * h + 4 * q;
+            const float4 w0 = *(const float4*)(cst), w1 = *(const float4*)(cst + GK), w2 = *(const float4*)(cst + 2 * GK),
+                         bb = *(const float4*)(cst + 3 * GK), mu = *(const float4*)(cst + 4 * GK),
+                         rs = *(const float4*)(cst + 5 * GK), ga = *(const float4*)(cst + 6 * GK),
+                         be = *(const float4*)(cst + 7 * GK);
+            a[q].x = __builtin_fmaxf(bn_pre(conv1_pre(w0.x, w1.x, w2.x, bb.x, x0, x1, x2), mu.x, rs.x, ga.x, be.x), 0.f);
+            a[q].y = __builtin_fmaxf(bn_pre(conv1_pre(w0.y, w1.y, w2.y, bb.y, x0, x1, x2), mu.y, rs.y, ga.y, be.y), 0.f);
+            a[q].z = __builtin_fmaxf(bn_pre(conv1_pre(w0.z, w1.z, w2.z, bb.z, x0, x1, x2), mu.z, rs.z, ga.z, be.z), 0.f);
+            a[q].w = __builtin_fmaxf(bn_pre(conv1_pre(w0.w, w1.w, w2.w, bb.w, x0, x1, x2), mu.w, rs.w, ga.w, be.w), 0.f);
+        }
+        if (rowA < M) {
+            float4* dst = (float4*)(h1 + (size_t)rowA * GK + 32 * h);
+#pragma unroll
+            for (int q = 0; q < GK / 8; ++q) dst[q] = a[q];
+        }
+        f32x16 acc[GNT];
+#pragma unroll
+        for (int t = 0; t < GNT; ++t) acc[t] = f32x16{0};
+#pragma unroll
+        for (int q = 0; q < GK / 8; ++q) {
+            const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* brow = sB + (32 * h + 4 * q + e) * GN + 32 * h + r;
+#pragma unroll
+                for (int t = 0; t < GNT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], brow[32 * t], acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int row0 = tile * 128 + wave * 32 + 4 * h;
+        int nvalid = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) nvalid += (row0 + (i & 3) + 8 * (i >> 2)) < M ? 1 : 0;
+#pragma unroll
+        for (int t = 0; t < GNT; ++t) {
+            float f1 = 0.f, f2 = 0.f;
+            if (cnt == 0.0 && nvalid > 0) a0[t] = acc[t][0] + bv[t];        // this lane's shift against cancellation
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + (i & 3) + 8 * (i >> 2);
+                if (row < M) {
+                    const float v = acc[t][i] + bv[t];
+                    const float d = v - a0[t];
+                    f1 += d;
+                    f2 += d * d;
+                    y2[(size_t)row * GN + 32 * t + r] = v;
+                }
+            }
+            s1[t] += (double)f1;
+            s2[t] += (double)f2;
+        }
+        cnt += (double)nvalid;
+    }
+
+    // per lane -> per workgroup: 8 lane records per column (4 waves x 2 halves), merged in a fixed order
+    __syncthreads();
+    double* red = (double*)g_smem;                     // [8][128][3]
+#pragma unroll
+    for (int t = 0; t < GNT; ++t) {
+        double* p = red + ((size_t)(wave * 2 + h) * GN + 32 * t + r) * 3;
+        const double mean = cnt > 0.0 ? (double)a0[t] + s1[t] / cnt : 0.0;
+        const double m2 = cnt > 0.0 ? s2[t] - s1[t] * s1[t] / cnt : 0.0;
+        p[0] = cnt;
+        p[1] = mean;
+        p[2] = m2 > 0.0 ? m2 : 0.0;
+    }
+    __syncthreads();
+    if (tid < GN) {
+        double n = 0.0, mean = 0.0, m2 = 0.0;
+        for (int k = 0; k < 8; ++k) {
+            const double* p = red + ((size_t)k * GN + tid) * 3;
+            const double nb = p[0], meanb = p[1], m2b = p[2];     // Chan et al.
+            if (nb == 0.0) continue;
+            const double nt = n + nb, d = meanb - mean;
+            mean += d * (nb / nt);
+            m2 += m2b + d * d * (n * nb / nt);
+            n = nt;
+        }
+        double* o = stat_rec + ((size_t)blockIdx.x * GN + tid) * 3;
+        o[0] = n;
+        o[1] = mean;
+        o[2] = m2;
+    }
+}
+
+// h1 [M,64] and y2 [M,128] out; stat_rec [tall_gemm_blocks(M)][128][3] doubles for t_stats_from_records.
+hipError_t launch_conv12_fwd(const float* X3, const float* W1, const float* b1, const float* mean1, const float* rstd1,
+                             const float* gamma1, const float* beta1, const float* W2, const float* b2, float* h1,
+                             float* y2, int M, double* stat_rec, hipStream_t s) {
+    if (!X3 || !W1 || !b1 || !W2 || !b2 || !h1 || !y2 || !stat_rec || M < 1) return hipErrorInvalidValue;
+    const size_t lds = G_LDS_BYTES > G_RED_BYTES ? G_LDS_BYTES : G_RED_BYTES;
+    hipError_t e = hipFuncSetAttribute((const void*)conv12_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv12_fwd_kernel, dim3(tall_gemm_blocks(M)), dim3(256), lds, s, X3, W1, b1, mean1, rstd1, gamma1,
+                       beta1, W2, b2, h1, y2, M, stat_rec);
+    return hipGetLastError();
 }
 
 // dh2 [M,128]: in dL/dh2 (before the ReLU mask), out dL/dy2.  dh1 [M,64]: dL/dh1 (before conv1's ReLU mask).

@@ -568,26 +568,36 @@ def test_conv3_on_float16_pieces_agrees_with_the_other_products(monkeypatch, act
 @pytest.mark.parametrize("P,B,k,seed", [(750, 24, 2, 21), (37, 150, 2, 22), (5, 16, 3, 23), (129, 3, 2, 24)])
 def test_backward_of_the_per_point_layers_in_one_pass_agrees_with_the_kernel_per_step_form(monkeypatch, P, B, k, seed):
     """By default the backward of conv2 / bn2 / relu and the column sums of bn1's backward run as one pass over dh2
-    (conv2_bwd_fused_kernel); PNGPD_TRAIN_BWD2=split runs a kernel per step.  Same state, same batch, same forward:
+    (conv2_bwd_fused_kernel) and the forward of conv1 / bn1 / relu / conv2 as one pass over the points
+    (conv12_fwd_kernel); PNGPD_TRAIN_BWD2=split and PNGPD_TRAIN_FWD12=split run a kernel per step.  Same state, same batch, same forward:
     both forms take identical ReLU decisions (the mask is the sign of the same recomputed expression), so every
     gradient agrees to float32 rounding of its sums - 2e-5 of the gradient's largest entry."""
     from pointnetgpd_amd import training
     x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal")).cuda()
     target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) * k).astype(np.int64)).cuda()
-    got = {}
+    got, fwd = {}, {}
     for form in ("split", "fused"):
         if form == "split":
             monkeypatch.setenv("PNGPD_TRAIN_BWD2", "split")
+            monkeypatch.setenv("PNGPD_TRAIN_FWD12", "split")
         else:
             monkeypatch.delenv("PNGPD_TRAIN_BWD2", raising=False)
+            monkeypatch.delenv("PNGPD_TRAIN_FWD12", raising=False)
         m = hip_train_model(P, k, seed, 1.3)
         logp, trans, ws, xc = training.train_forward(m, x)
+        fwd[form] = [logp.cpu().clone(), trans.cpu().clone()] + [
+            training.saved_activation(ws, B, P, k, n).cpu().clone() for n in training.SAVED]
+        fwd[form] += [b.detach().cpu().clone() for b in m.buffers()]
         loss, dlogp = nll_loss(logp, target)
         grads = {n: torch.zeros_like(p) for n, p in m.named_parameters()}
         by_id = {id(p): grads[n] for n, p in m.named_parameters()}
         training.train_backward(m, xc, logp, dlogp, None, ws, lambda p: by_id[id(p)])
         torch.cuda.synchronize()
         got[form] = {n: g.double().cpu() for n, g in grads.items()}
+    # the forward of conv1 / bn1 / relu / conv2 in one pass (conv12_fwd_kernel) runs the same operations in the same
+    # order as the two-kernel form: outputs, saved activations and running statistics are equal bit for bit
+    for a, b in zip(fwd["split"], fwd["fused"]):
+        assert torch.equal(a, b)
     worst = ("", 0.0)
     for n, ref in got["split"].items():
         g = got["fused"][n]
