@@ -181,11 +181,12 @@ inline int t_gram_chunks(int M) { return (M + t_gram_rows_per_chunk(M) - 1) / t_
 // doubles of the Gram workspace: per chunk a 128x128 partial matrix and 128 column sums
 inline size_t t_gram_ws_doubles(int M) { return (size_t)t_gram_chunks(M) * (C2 * C2 + C2); }
 
-hipError_t t_points_to_rows(const float* x, const float* trans, float* X3, int B, int P, hipStream_t s);
 int t_x3_blocks(int M);
 hipError_t t_conv1_bn_fwd(const float* X3, const float* W1, const float* b1, const float* gamma, const float* beta,
                           float momentum, double* part, float* mean, float* rstd, float* running_mean,
                           float* running_var, float* h1, int M, hipStream_t s);
+hipError_t t_points_to_rows_moments(const float* x, const float* trans, float* X3, int B, int P, double* part,
+                                    hipStream_t s);
 hipError_t t_fc_bn_fwd(const float* X, const float* W, const float* b, const float* gamma, const float* beta, int M,
                        int N, int K, float momentum, double* part, float* splitk_part, float* Z, float* A, float* mean,
                        float* rstd, float* running_mean, float* running_var, hipStream_t s);

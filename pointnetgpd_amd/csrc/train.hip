@@ -28,26 +28,6 @@ constexpr float BN_EPS = 1e-5f;
 // ---------------------------------------------------------------------------------------------
 // points -> rows, first layer
 // ---------------------------------------------------------------------------------------------
-// X3[m, c] = sum_j x[b, j, p] * T[b, j, c]   (T = identity when trans == nullptr); m = b*P + p
-__global__ void k_points_to_rows(const float* __restrict__ x, const float* __restrict__ trans,
-                                 float* __restrict__ X3, int B, int P) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= B * P) return;
-    const int b = m / P, p = m - b * P;
-    const float* xb = x + (size_t)b * 3 * P;
-    const float x0 = xb[p], x1 = xb[P + p], x2 = xb[2 * P + p];
-    float o0 = x0, o1 = x1, o2 = x2;
-    if (trans != nullptr) {
-        const float* T = trans + (size_t)b * 9;
-        o0 = x0 * T[0] + x1 * T[3] + x2 * T[6];
-        o1 = x0 * T[1] + x1 * T[4] + x2 * T[7];
-        o2 = x0 * T[2] + x1 * T[5] + x2 * T[8];
-    }
-    X3[(size_t)m * 3 + 0] = o0;
-    X3[(size_t)m * 3 + 1] = o1;
-    X3[(size_t)m * 3 + 2] = o2;
-}
-
 // ---------------------------------------------------------------------------------------------
 // conv1 + train-mode BatchNorm + ReLU in one pass over the points (model/pointnet.py:30, :143).
 // y1 = W1 x + b1 is linear in the 3 coordinates, so its batch statistics follow from the first and second
@@ -55,16 +35,33 @@ __global__ void k_points_to_rows(const float* __restrict__ x, const float* __res
 // ---------------------------------------------------------------------------------------------
 constexpr int X3M_ROWS = 1024;      // rows per block of the moment sums
 
-// part[blk][9] = sums over the block's rows of x, y, z, xx, xy, xz, yy, yz, zz (double)
-__global__ __launch_bounds__(256) void k_x3_moments(const float* __restrict__ X3, int M, double* __restrict__ part) {
+// X3[m, c] = sum_j x[b, j, p] * T[b, j, c]   (T = identity when trans == nullptr); m = b*P + p, and the moment sums
+// of the rows: part[blk][9] = sums over the block's X3M_ROWS rows of x, y, z, xx, xy, xz, yy, yz, zz (double)
+__global__ __launch_bounds__(256) void k_points_rows_moments(const float* __restrict__ x, const float* __restrict__ trans,
+                                                             float* __restrict__ X3, int B, int P,
+                                                             double* __restrict__ part) {
     __shared__ double sh[4][9];
+    const int M = B * P;
     const int r0 = blockIdx.x * X3M_ROWS, r1 = min(M, r0 + X3M_ROWS);
     double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = r0 + threadIdx.x; r < r1; r += 256) {
-        const double x = X3[(size_t)r * 3], y = X3[(size_t)r * 3 + 1], z = X3[(size_t)r * 3 + 2];
-        a[0] += x; a[1] += y; a[2] += z;
-        a[3] += x * x; a[4] += x * y; a[5] += x * z;
-        a[6] += y * y; a[7] += y * z; a[8] += z * z;
+    for (int m = r0 + threadIdx.x; m < r1; m += 256) {
+        const int b = m / P, p = m - b * P;
+        const float* xb = x + (size_t)b * 3 * P;
+        const float x0 = xb[p], x1 = xb[P + p], x2 = xb[2 * P + p];
+        float o0 = x0, o1 = x1, o2 = x2;
+        if (trans != nullptr) {
+            const float* T = trans + (size_t)b * 9;
+            o0 = x0 * T[0] + x1 * T[3] + x2 * T[6];
+            o1 = x0 * T[1] + x1 * T[4] + x2 * T[7];
+            o2 = x0 * T[2] + x1 * T[5] + x2 * T[8];
+        }
+        X3[(size_t)m * 3 + 0] = o0;
+        X3[(size_t)m * 3 + 1] = o1;
+        X3[(size_t)m * 3 + 2] = o2;
+        const double dx = o0, dy = o1, dz = o2;
+        a[0] += dx; a[1] += dy; a[2] += dz;
+        a[3] += dx * dx; a[4] += dx * dy; a[5] += dx * dz;
+        a[6] += dy * dy; a[7] += dy * dz; a[8] += dz * dz;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -930,18 +927,20 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 static inline int colreduce_grid_x(int C) { return (C / 4 + 63) / 64; }   // blocks of up to 64 column quads
 static inline dim3 grid1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
-hipError_t t_points_to_rows(const float* x, const float* trans, float* X3, int B, int P, hipStream_t s) {
-    hipLaunchKernelGGL(k_points_to_rows, grid1((size_t)B * P), dim3(256), 0, s, x, trans, X3, B, P);
+int t_x3_blocks(int M) { return (M + X3M_ROWS - 1) / X3M_ROWS; }
+// rows of points (through the candidate's transform, if given) and their moment sums in part (t_x3_blocks(B*P) * 9
+// doubles), which t_conv1_bn_fwd turns into conv1's batch statistics
+hipError_t t_points_to_rows_moments(const float* x, const float* trans, float* X3, int B, int P, double* part,
+                                    hipStream_t s) {
+    hipLaunchKernelGGL(k_points_rows_moments, dim3(t_x3_blocks(B * P)), dim3(256), 0, s, x, trans, X3, B, P, part);
     return hipGetLastError();
 }
-// conv1 + BatchNorm (batch statistics from the moments of the points) + ReLU: writes h1, mean, rstd and updates the
-// running statistics.  part: t_x3_blocks(M) * 9 doubles.
-int t_x3_blocks(int M) { return (M + X3M_ROWS - 1) / X3M_ROWS; }
+// conv1 + BatchNorm + ReLU: batch statistics from the moment sums t_points_to_rows_moments left in part (mean, rstd,
+// running statistics updated) and, when h1 is given, the activation itself.
 hipError_t t_conv1_bn_fwd(const float* X3, const float* W1, const float* b1, const float* gamma, const float* beta,
                           float momentum, double* part, float* mean, float* rstd, float* running_mean,
                           float* running_var, float* h1, int M, hipStream_t s) {
     const int nblk = t_x3_blocks(M);
-    hipLaunchKernelGGL(k_x3_moments, dim3(nblk), dim3(256), 0, s, X3, M, part);
     hipLaunchKernelGGL(k_conv1_stats, dim3(1), dim3(576), 0, s, (const double*)part, nblk, M, W1, b1, momentum, mean, rstd,
                        running_mean, running_var);
     if (h1 == nullptr) return hipGetLastError();      // statistics only: the caller makes h1 where it is consumed

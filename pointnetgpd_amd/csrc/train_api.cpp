@@ -152,7 +152,7 @@ int check_shape(int B, int P, int k, const void* ws, size_t ws_bytes) {
 int fwd_stack(StackWs& S, float* const* p, int u1, const float* x, const float* trans, int B, int P, int relu_out,
               float momentum, double* part, double* gram_part, hipStream_t s) {
     const int M = B * P;
-    HIP_TRY(pngpd::t_points_to_rows(x, trans, S.X3, B, P, s));
+    HIP_TRY(pngpd::t_points_to_rows_moments(x, trans, S.X3, B, P, part, s));
     // bn1's statistics from the moments of the points; then conv1 + bn1 + relu + conv2 in one pass that writes h1 and
     // y2 and takes the column statistics of y2 from the accumulators (PNGPD_TRAIN_FWD12=split: h1 by a pass of its own,
     // conv2 as a tall product reading it).  relu(bn(conv2)) is applied by the first pass of the conv3 block (t_conv3_fwd)
