@@ -251,6 +251,9 @@ hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const 
 hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s,
                      float* splitk_part = nullptr);
 hipError_t t_gemm_tn(const float* dY, const float* Hm, float* part, float* dW, int M, int N, int K, hipStream_t s);
+// both of the above for one linear layer [N out, K in] in one launch: dW[N,K] = dY^T Hm, dX[M,K] = dY W
+hipError_t t_gemm_tn_nn(const float* dY, const float* Hm, float* tn_part, float* dW, const float* W, float* dX, int M,
+                        int N, int K, hipStream_t s, float* splitk_part = nullptr);
 hipError_t t_conv1_bwd(const float* dy1, const float* X3, const float* W1, int M, double* part, float* dW1,
                        float* dX3, hipStream_t s);
 hipError_t t_trans_grad(const float* x, const float* dX3, int B, int P, const float* dtrans_ext, float* dtrans,

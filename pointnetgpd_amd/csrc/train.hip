@@ -605,14 +605,15 @@ constexpr int GB_M = 64, GB_N = 64, GB_K = 32;
 
 // dX[M,Kout] = dY[M,N] W[N,Kout];  Kout % 64 == 0, N % 32 == 0.
 // optional fused mask: dX *= (Hmask > 0) is NOT applied here (BN backward needs the unmasked sums).
-__global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ dY, const float* __restrict__ W,
-                                                      float* __restrict__ dX, int M, int N, int Kout,
-                                                      float* __restrict__ part) {
+// (bx, by, bz) of (gx, gy, gz): the workgroup's place in the product's grid (Kout/64, ceil(M/64), slices)
+__device__ __forceinline__ void gemm_nn_block(const float* __restrict__ dY, const float* __restrict__ W,
+                                              float* __restrict__ dX, int M, int N, int Kout, float* __restrict__ part,
+                                              int bx, int by, int bz, int gz) {
     __shared__ float sA[GB_M * (GB_K + 1)];
     __shared__ float sB[GB_K * GB_N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GB_M, k0 = blockIdx.x * GB_N;
+    const int m0 = by * GB_M, k0 = bx * GB_N;
     const int arow = tid >> 3, acol = (tid & 7) * 4;        // A tile 64x32: 2 float4 per thread
     const int brow = tid >> 4, bcol = (tid & 15) * 4;       // B tile 32x64: 2 float4 per thread
     f32x16 acc = {0};
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
         }
     };
     // split over the summed dimension: slice blockIdx.z of gridDim.z writes a partial product (launch_splitk_reduce)
-    const int n_len = N / (int)gridDim.z, n_begin = (int)blockIdx.z * n_len, n_end = n_begin + n_len;
+    const int n_len = N / gz, n_begin = bz * n_len, n_end = n_begin + n_len;
     load_tile(n_begin);
     for (int n0 = n_begin; n0 < n_end; n0 += GB_K) {
         __syncthreads();
@@ -648,21 +649,27 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (row < M) (part != nullptr ? part + (size_t)blockIdx.z * M * Kout : dX)[(size_t)row * Kout + col] = acc[i];
+        if (row < M) (part != nullptr ? part + (size_t)bz * M * Kout : dX)[(size_t)row * Kout + col] = acc[i];
     }
+}
+
+__global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ dY, const float* __restrict__ W,
+                                                      float* __restrict__ dX, int M, int N, int Kout,
+                                                      float* __restrict__ part) {
+    gemm_nn_block(dY, W, dX, M, N, Kout, part, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
 }
 
 // partial dW[chunk][N,K] = dY[rows of chunk, N]^T H[rows of chunk, K];  N % 64 == 0, K % 64 == 0
 // grid (K/64, N/64, chunks); rows_per_chunk % 32 == 0
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dY, const float* __restrict__ Hm,
-                                                      float* __restrict__ part, int M, int N, int K,
-                                                      int rows_per_chunk) {
+__device__ __forceinline__ void gemm_tn_block(const float* __restrict__ dY, const float* __restrict__ Hm,
+                                              float* __restrict__ part, int M, int N, int K, int rows_per_chunk, int bx,
+                                              int by, int bz) {
     __shared__ float sA[GB_K * GB_M];   // [m][n] 32 x 64
     __shared__ float sB[GB_K * GB_N];   // [m][k] 32 x 64
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    const int row_begin = blockIdx.z * rows_per_chunk;
+    const int k0 = bx * 64, n0 = by * 64;
+    const int row_begin = bz * rows_per_chunk;
     const int row_end = min(M, row_begin + rows_per_chunk);
     const int lrow = tid >> 4, lcol = (tid & 15) * 4;        // 32x64 tile: 2 float4 per thread
     f32x16 acc = {0};
@@ -692,12 +699,38 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         for (int s = 0; s < GB_K / 2; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[2 * s * GB_M], rb[2 * s * GB_N], acc, 0, 0, 0);
     }
-    float* out = part + (size_t)blockIdx.z * N * K;
+    float* out = part + (size_t)bz * N * K;
     const int col = k0 + wn * 32 + r;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int row = n0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         out[(size_t)row * K + col] = acc[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dY, const float* __restrict__ Hm,
+                                                      float* __restrict__ part, int M, int N, int K,
+                                                      int rows_per_chunk) {
+    gemm_tn_block(dY, Hm, part, M, N, K, rows_per_chunk, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Both products of a linear layer's backward in one launch - they share dY and nothing else, and at a few hundred
+// rows neither fills the chip: workgroups [0, n_tn) take the weight-gradient product's grid (K/64, N/64, chunks),
+// the rest the input-gradient product's (K/64, ceil(M/64), slices).
+__global__ __launch_bounds__(256) void gemm_tn_nn_kernel(const float* __restrict__ dY, const float* __restrict__ Hm,
+                                                         float* __restrict__ tn_out, const float* __restrict__ W,
+                                                         float* __restrict__ dX, float* __restrict__ nn_part, int M,
+                                                         int N, int K, int rows_per_chunk, int n_tn, int nn_slices) {
+    const int kx = K / 64;
+    int b = blockIdx.x;
+    if (b < n_tn) {
+        const int bx = b % kx, by = (b / kx) % (N / 64), bz = b / (kx * (N / 64));
+        gemm_tn_block(dY, Hm, tn_out, M, N, K, rows_per_chunk, bx, by, bz);
+    } else {
+        b -= n_tn;
+        const int my = (M + 63) / 64;
+        const int bx = b % kx, by = (b / kx) % my, bz = b / (kx * my);
+        gemm_nn_block(dY, W, dX, M, N, K, nn_part, bx, by, bz, nn_slices);
     }
 }
 
@@ -1073,6 +1106,27 @@ hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, i
     return launch_splitk_reduce(splitk_part, ks, M, Kout, nullptr, 0, dX, s);
 }
 int t_tn_chunks(int M) { return (M + TN_ROWS_PER_CHUNK - 1) / TN_ROWS_PER_CHUNK; }
+
+// t_gemm_tn(dY, Hm -> dW) and t_gemm_nn(dY, W -> dX) of one linear layer [N out, K in] as one launch (plus the
+// reductions of their partial products, if any)
+hipError_t t_gemm_tn_nn(const float* dY, const float* Hm, float* tn_part, float* dW, const float* W, float* dX, int M,
+                        int N, int K, hipStream_t s, float* splitk_part) {
+    if (N % 64 != 0 || K % 64 != 0) return hipErrorInvalidValue;
+    const int chunks = t_tn_chunks(M);
+    const int n_tn = (K / 64) * (N / 64) * chunks;
+    const int nn_tiles = (K / 64) * ((M + 63) / 64);
+    int ks = splitk_part != nullptr ? splitk_factor(nn_tiles, N / GB_K) : 1;
+    if ((size_t)ks * M * K > SPLITK_PART_FLOATS) ks = 1;
+    hipLaunchKernelGGL(gemm_tn_nn_kernel, dim3(n_tn + nn_tiles * ks), dim3(256), 0, s, dY, Hm, chunks == 1 ? dW : tn_part,
+                       W, dX, ks > 1 ? splitk_part : (float*)nullptr, M, N, K, TN_ROWS_PER_CHUNK, n_tn, ks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (chunks > 1)
+        hipLaunchKernelGGL(k_reduce_chunks, grid1((size_t)N * K, 16), dim3(256), 0, s, (const float*)tn_part, chunks,
+                           (size_t)N * K, dW);
+    if (ks > 1) return launch_splitk_reduce(splitk_part, ks, M, K, nullptr, 0, dX, s);
+    return hipGetLastError();
+}
 
 hipError_t t_gemm_tn(const float* dY, const float* Hm, float* part, float* dW, int M, int N, int K, hipStream_t s) {
     if (N % 64 != 0 || K % 64 != 0) return hipErrorInvalidValue;

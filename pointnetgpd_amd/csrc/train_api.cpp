@@ -209,14 +209,14 @@ int bwd_fc(FcWs& F, const float* const* p, float* const* g, int u1, const float*
     HIP_TRY(pngpd::t_bn_bwd(F.da2, F.a2, F.z2, F.mean[1], F.rstd[1], cslot(p, u1 + 1, PNGPD_F_BN_WEIGHT), B, 256,
                             W.part, W.m1, W.m2, slot(g, u1 + 1, PNGPD_F_BN_WEIGHT), slot(g, u1 + 1, PNGPD_F_BN_BIAS),
                             slot(g, u1 + 1, PNGPD_F_BIAS), s));
-    HIP_TRY(pngpd::t_gemm_tn(F.da2, F.a1, W.tn_part, slot(g, u1 + 1, PNGPD_F_WEIGHT), B, 256, 512, s));
-    HIP_TRY(pngpd::t_gemm_nn(F.da2, cslot(p, u1 + 1, PNGPD_F_WEIGHT), F.da1, B, 256, 512, s, W.fc_part));
+    HIP_TRY(pngpd::t_gemm_tn_nn(F.da2, F.a1, W.tn_part, slot(g, u1 + 1, PNGPD_F_WEIGHT), cslot(p, u1 + 1, PNGPD_F_WEIGHT),
+                                F.da1, B, 256, 512, s, W.fc_part));
     // layer 1
     HIP_TRY(pngpd::t_bn_bwd(F.da1, F.a1, F.z1, F.mean[0], F.rstd[0], cslot(p, u1, PNGPD_F_BN_WEIGHT), B, 512, W.part,
                             W.m1, W.m2, slot(g, u1, PNGPD_F_BN_WEIGHT), slot(g, u1, PNGPD_F_BN_BIAS),
                             slot(g, u1, PNGPD_F_BIAS), s));
-    HIP_TRY(pngpd::t_gemm_tn(F.da1, in, W.tn_part, slot(g, u1, PNGPD_F_WEIGHT), B, 512, 1024, s));
-    HIP_TRY(pngpd::t_gemm_nn(F.da1, cslot(p, u1, PNGPD_F_WEIGHT), F.din, B, 512, 1024, s, W.fc_part));
+    HIP_TRY(pngpd::t_gemm_tn_nn(F.da1, in, W.tn_part, slot(g, u1, PNGPD_F_WEIGHT), cslot(p, u1, PNGPD_F_WEIGHT), F.din, B,
+                                512, 1024, s, W.fc_part));
     return PNGPD_OK;
 }
 
