@@ -863,9 +863,9 @@ __global__ __launch_bounds__(256) void k_trans_grad(const float* __restrict__ x,
 }
 
 // tiny-output layer backward (N <= 16, K = 256):  dA[m,k] = sum_n dZ[m,n] W[n,k]
-__global__ void k_small_dgrad(const float* __restrict__ dZ, const float* __restrict__ W, float* __restrict__ dA,
-                              int M, int N, int K) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void small_dgrad_block(const float* __restrict__ dZ, const float* __restrict__ W,
+                                                  float* __restrict__ dA, int M, int N, int K, int block) {
+    const size_t i = (size_t)block * 256 + threadIdx.x;
     if (i >= (size_t)M * K) return;
     const int k = (int)(i % K);
     const size_t m = i / K;
@@ -877,12 +877,12 @@ __global__ void k_small_dgrad(const float* __restrict__ dZ, const float* __restr
 // dW[n,k] = sum_m dZ[m,n] A[m,k];  db[n] = sum_m dZ[m,n]     (M = batch)
 // block = 16 k x 16 row lanes, grid (K/16, N): every row lane sums every 16th row, the lane sums are added in a
 // fixed order
-__global__ __launch_bounds__(256) void k_small_wgrad(const float* __restrict__ dZ, const float* __restrict__ A,
-                                                     float* __restrict__ dW, float* __restrict__ db, int M, int N,
-                                                     int K) {
+__device__ __forceinline__ void small_wgrad_block(const float* __restrict__ dZ, const float* __restrict__ A,
+                                                  float* __restrict__ dW, float* __restrict__ db, int M, int N, int K,
+                                                  int bx, int n) {
     __shared__ float sw[16][16], sb[16];
     const int kl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int k = blockIdx.x * 16 + kl, n = blockIdx.y;
+    const int k = bx * 16 + kl;
     float s = 0.f, b = 0.f;
     if (k < K) {
 #pragma unroll 4
@@ -899,10 +899,24 @@ __global__ __launch_bounds__(256) void k_small_wgrad(const float* __restrict__ d
     float t = 0.f;
     for (int i = 0; i < 16; ++i) t += sw[i][kl];
     if (k < K) dW[(size_t)n * K + k] = t;
-    if (blockIdx.x == 0 && kl == 0) {
+    if (bx == 0 && kl == 0) {
         float u = 0.f;
         for (int i = 0; i < 16; ++i) u += sb[i];
         db[n] = u;
+    }
+}
+
+// both in one launch: workgroups [0, n_dgrad) make dA, the rest dW and db (grid (K/16, N) of the latter, row-major)
+__global__ __launch_bounds__(256) void k_small_bwd(const float* __restrict__ dZ, const float* __restrict__ A,
+                                                   const float* __restrict__ W, float* __restrict__ dA,
+                                                   float* __restrict__ dW, float* __restrict__ db, int M, int N, int K,
+                                                   int n_dgrad) {
+    const int b = blockIdx.x;
+    if (b < n_dgrad) {
+        small_dgrad_block(dZ, W, dA, M, N, K, b);
+    } else {
+        const int kx = (K + 15) / 16;
+        small_wgrad_block(dZ, A, dW, db, M, N, K, (b - n_dgrad) % kx, (b - n_dgrad) / kx);
     }
 }
 
@@ -1158,8 +1172,9 @@ hipError_t t_trans_grad(const float* x, const float* dX3, int B, int P, const fl
 }
 hipError_t t_small_bwd(const float* dZ, const float* A, const float* W, float* dA, float* dW, float* db, int M, int N,
                        int K, hipStream_t s) {
-    hipLaunchKernelGGL(k_small_dgrad, grid1((size_t)M * K), dim3(256), 0, s, dZ, W, dA, M, N, K);
-    hipLaunchKernelGGL(k_small_wgrad, dim3((K + 15) / 16, N), dim3(256), 0, s, dZ, A, dW, db, M, N, K);
+    const int n_dgrad = (int)(((size_t)M * K + 255) / 256);
+    hipLaunchKernelGGL(k_small_bwd, dim3(n_dgrad + (K + 15) / 16 * N), dim3(256), 0, s, dZ, A, W, dA, dW, db, M, N, K,
+                       n_dgrad);
     return hipGetLastError();
 }
 hipError_t t_logsoftmax_bwd(const float* logp, const float* dlogp, float* dlogits, int B, int k, hipStream_t s) {
