@@ -247,7 +247,12 @@ hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const 
                        const float* dpooled,
                        const float* pooled, const int* arg, const float* mean, const float* rstd, int B, int P,
                        int relu_out, const Conv3Ws& w, float* m1, float* m2, float* dW3, float* db3_zero, float* dgamma,
-                       float* dbeta, float* dh2, hipStream_t s);
+                       float* dbeta, float* dh2, hipStream_t s, const float* bn2_y = nullptr,
+                       const float* bn2_mean = nullptr, const float* bn2_rstd = nullptr, const float* bn2_gamma = nullptr,
+                       const float* bn2_beta = nullptr, double* bn2_part = nullptr);
+// the finalize step of t_bn_bwd alone: partial column sums ([nblk][2][C] doubles) -> m1, m2, dgamma, dbeta
+hipError_t t_bn_bwd_finalize(const double* part, int nblk, int M, int C, float* m1, float* m2, float* dgamma,
+                             float* dbeta, float* dbias_zero, hipStream_t s);
 hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s,
                      float* splitk_part = nullptr);
 hipError_t t_gemm_tn(const float* dY, const float* Hm, float* part, float* dW, int M, int N, int K, hipStream_t s);

@@ -1092,6 +1092,12 @@ hipError_t t_bn_bwd_sums(const float* dh, const float* y, const float* mean, con
                        dbias_zero);
     return hipGetLastError();
 }
+hipError_t t_bn_bwd_finalize(const double* part, int nblk, int M, int C, float* m1, float* m2, float* dgamma,
+                             float* dbeta, float* dbias_zero, hipStream_t s) {
+    hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta,
+                       dbias_zero);
+    return hipGetLastError();
+}
 // the second half of t_bn_bwd for conv1's BatchNorm with the column sums already in part ([nblk][2][64] doubles),
 // followed by t_conv1_bwd, without storing dy1: dW1 and (dX3 != nullptr) dX3.  part is reused for the partial sums
 // of dW1 and must hold t_red_blocks(M) * 192 doubles.

@@ -223,18 +223,21 @@ int bwd_fc(FcWs& F, const float* const* p, float* const* g, int u1, const float*
 int bwd_stack(StackWs& S, const float* const* p, float* const* g, int u1, const float* dpooled, int B, int P,
               int relu_out, bool need_dX3, TrainWs& W, hipStream_t s) {
     const int M = B * P;
-    // conv3 / bn3 / max-pool
+    // PNGPD_TRAIN_BWD2=split: one kernel per step of the backward of the layers in front of conv3, as before
+    const char* bwd2_env = getenv("PNGPD_TRAIN_BWD2");
+    const bool fused = !(bwd2_env && bwd2_env[0] == 's');
+    // conv3 / bn3 / max-pool; its last launch (conv3's weight gradient) also sums the columns for bn2's backward
     HIP_TRY(pngpd::t_conv3_bwd(S.h2, cslot(p, u1 + 2, PNGPD_F_WEIGHT), cslot(p, u1 + 2, PNGPD_F_BIAS),
                                cslot(p, u1 + 2, PNGPD_F_BN_WEIGHT), cslot(p, u1 + 2, PNGPD_F_BN_BIAS), dpooled, S.pooled, S.arg, S.mean[2], S.rstd[2], B, P,
                                relu_out, S.c3, W.m1, W.m2, slot(g, u1 + 2, PNGPD_F_WEIGHT), slot(g, u1 + 2, PNGPD_F_BIAS),
-                               slot(g, u1 + 2, PNGPD_F_BN_WEIGHT), slot(g, u1 + 2, PNGPD_F_BN_BIAS), S.dh2, s));
-    // conv2 / bn2 / conv1's bn in one pass over dh2 (PNGPD_TRAIN_BWD2=split: one kernel per step, as before)
-    const char* bwd2_env = getenv("PNGPD_TRAIN_BWD2");
-    if (!(bwd2_env && bwd2_env[0] == 's')) {
-        HIP_TRY(pngpd::t_bn_bwd_sums(S.dh2, S.y2, S.mean[1], S.rstd[1], cslot(p, u1 + 1, PNGPD_F_BN_WEIGHT),
-                                     cslot(p, u1 + 1, PNGPD_F_BN_BIAS), M, C2, W.part, W.m1, W.m2,
-                                     slot(g, u1 + 1, PNGPD_F_BN_WEIGHT), slot(g, u1 + 1, PNGPD_F_BN_BIAS),
-                                     slot(g, u1 + 1, PNGPD_F_BIAS), s));
+                               slot(g, u1 + 2, PNGPD_F_BN_WEIGHT), slot(g, u1 + 2, PNGPD_F_BN_BIAS), S.dh2, s,
+                               fused ? S.y2 : nullptr, S.mean[1], S.rstd[1], cslot(p, u1 + 1, PNGPD_F_BN_WEIGHT),
+                               cslot(p, u1 + 1, PNGPD_F_BN_BIAS), fused ? W.part : nullptr));
+    // conv2 / bn2 / conv1's bn in one pass over dh2
+    if (fused) {
+        HIP_TRY(pngpd::t_bn_bwd_finalize(W.part, pngpd::t_colreduce_blocks(M), M, C2, W.m1, W.m2,
+                                         slot(g, u1 + 1, PNGPD_F_BN_WEIGHT), slot(g, u1 + 1, PNGPD_F_BN_BIAS),
+                                         slot(g, u1 + 1, PNGPD_F_BIAS), s));
         HIP_TRY(pngpd::launch_conv2_bwd_fused(S.dh2, S.y2, S.mean[1], S.rstd[1], cslot(p, u1 + 1, PNGPD_F_BN_WEIGHT),
                                               cslot(p, u1 + 1, PNGPD_F_BN_BIAS), W.m1, W.m2,
                                               cslot(p, u1 + 1, PNGPD_F_WEIGHT), S.dh1, M, S.X3,

@@ -1290,41 +1290,111 @@ __global__ __launch_bounds__(1024) void k_conv3_sparse_dgrad(const float* __rest
     }
 }
 
-// dW[c,j] = A_c sum_b g[b,c] h[arg(b,c), j] + M (p_c abar_j + q_c sum_i W[c,i] Cov[i][j]); block per channel
-__global__ __launch_bounds__(128) void k_conv3_wgrad(const float* __restrict__ h, const float* __restrict__ W3,
-                                                     const float* __restrict__ gamma, const float* __restrict__ rstd,
-                                                     const float* __restrict__ m1, const float* __restrict__ m2,
-                                                     const float* __restrict__ gmask, const int* __restrict__ arg,
-                                                     const double* __restrict__ cov, const double* __restrict__ abar_d,
-                                                     int B, int P, float* __restrict__ dW) {
-    __shared__ float s_g[128];
-    __shared__ int s_r[128];
-    __shared__ double s_w[C2];
-    const int c = blockIdx.x, j = threadIdx.x;
-    s_w[j] = (double)W3[(size_t)c * C2 + j];
+// dW[c,j] = A_c sum_b g[b,c] h[arg(b,c), j] + M (p_c abar_j + q_c sum_i W[c,i] Cov[i][j]); 128 threads per channel,
+// two channels (2 blk, 2 blk + 1) per workgroup of 256
+__device__ __forceinline__ void conv3_wgrad_block(const float* __restrict__ h, const float* __restrict__ W3,
+                                                  const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                  const float* __restrict__ m1, const float* __restrict__ m2,
+                                                  const float* __restrict__ gmask, const int* __restrict__ arg,
+                                                  const double* __restrict__ cov, const double* __restrict__ abar_d,
+                                                  int B, int P, float* __restrict__ dW, int blk) {
+    __shared__ float s_g[2][128];
+    __shared__ int s_r[2][128];
+    __shared__ double s_w[2][C2];
+    const int half = threadIdx.x >> 7, j = threadIdx.x & 127, c = 2 * blk + half;
+    s_w[half][j] = (double)W3[(size_t)c * C2 + j];
     double sparse = 0.0;
     for (int b0 = 0; b0 < B; b0 += 128) {
         __syncthreads();
         const int bb = b0 + j;
         if (bb < B) {
-            s_g[j] = gmask[(size_t)bb * C3 + c];
-            s_r[j] = bb * P + arg[(size_t)bb * C3 + c];
+            s_g[half][j] = gmask[(size_t)bb * C3 + c];
+            s_r[half][j] = bb * P + arg[(size_t)bb * C3 + c];
         }
         __syncthreads();
         const int n = min(128, B - b0);
         float acc = 0.f;
 #pragma unroll 8
-        for (int t = 0; t < n; ++t) acc = fmaf(s_g[t], h[(size_t)s_r[t] * C2 + j], acc);
+        for (int t = 0; t < n; ++t) acc = fmaf(s_g[half][t], h[(size_t)s_r[half][t] * C2 + j], acc);
         sparse += (double)acc;
     }
     __syncthreads();
     double dense = 0.0;
 #pragma unroll 8
-    for (int i = 0; i < C2; ++i) dense += s_w[i] * cov[(size_t)i * C2 + j];
+    for (int i = 0; i < C2; ++i) dense += s_w[half][i] * cov[(size_t)i * C2 + j];
     const double M = (double)B * P;
     const double A = (double)gamma[c] * (double)rstd[c];
     const double p = -A * (double)m1[c], q = -A * (double)rstd[c] * (double)m2[c];
     dW[(size_t)c * C2 + j] = (float)(A * sparse + M * (p * abar_d[j] + q * dense));
+}
+
+// Column sums for the backward of the BatchNorm in FRONT of conv3 (128 channels, ReLU behind it), over the rows
+// [blk rows_per_block, ...): s1 = sum g, s2 = sum g yhat with g = dh masked by the sign of the recomputed
+// pre-activation and yhat = (y - mean) rstd.  part [nblk][2][128] doubles, as k_colreduce writes them.
+// 256 threads = 32 column quads x 8 row lanes.
+__device__ __forceinline__ void bn2_bwd_sums_block(const float* __restrict__ dh, const float* __restrict__ y,
+                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int M,
+                                                   int rows_per_block, double* __restrict__ part, int blk) {
+    __shared__ double red[2][8][C2];
+    const int ql = threadIdx.x & 31, rl = threadIdx.x >> 5, col = ql * 4;
+    const int r0 = blk * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const float4 mu = *(const float4*)(mean + col), rs = *(const float4*)(rstd + col);
+    const float4 ga = make_float4(gamma[col], gamma[col + 1], gamma[col + 2], gamma[col + 3]);
+    const float4 be = make_float4(beta[col], beta[col + 1], beta[col + 2], beta[col + 3]);
+    float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += 8) {
+        float4 g = *(const float4*)(dh + (size_t)r * C2 + col);
+        const float4 yv = *(const float4*)(y + (size_t)r * C2 + col);
+        if (!(bn_pre(yv.x, mu.x, rs.x, ga.x, be.x) > 0.f)) g.x = 0.f;
+        if (!(bn_pre(yv.y, mu.y, rs.y, ga.y, be.y) > 0.f)) g.y = 0.f;
+        if (!(bn_pre(yv.z, mu.z, rs.z, ga.z, be.z) > 0.f)) g.z = 0.f;
+        if (!(bn_pre(yv.w, mu.w, rs.w, ga.w, be.w) > 0.f)) g.w = 0.f;
+        s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+        s2.x += g.x * ((yv.x - mu.x) * rs.x);
+        s2.y += g.y * ((yv.y - mu.y) * rs.y);
+        s2.z += g.z * ((yv.z - mu.z) * rs.z);
+        s2.w += g.w * ((yv.w - mu.w) * rs.w);
+    }
+    double* d1 = &red[0][rl][col];
+    double* d2 = &red[1][rl][col];
+    d1[0] = (double)s1.x; d1[1] = (double)s1.y; d1[2] = (double)s1.z; d1[3] = (double)s1.w;
+    d2[0] = (double)s2.x; d2[1] = (double)s2.y; d2[2] = (double)s2.z; d2[3] = (double)s2.w;
+    __syncthreads();
+    if (threadIdx.x < C2) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < 8; ++k) {          // fixed order: reproducible
+            a += red[0][k][threadIdx.x];
+            b += red[1][k][threadIdx.x];
+        }
+        part[((size_t)blk * 2 + 0) * C2 + threadIdx.x] = a;
+        part[((size_t)blk * 2 + 1) * C2 + threadIdx.x] = b;
+    }
+}
+
+// conv3's weight gradient and - independent of it, and bound by memory where the former is bound by the latency of
+// its row gathers - the column sums of the BatchNorm backward that follows, in one launch: workgroups [0, C3/2) take
+// two channels of dW each, the rest the row blocks of the sums (bn_y == nullptr: no sums, grid = C3/2).
+__global__ __launch_bounds__(256) void k_conv3_wgrad_bn2sums(const float* __restrict__ h, const float* __restrict__ W3,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ rstd, const float* __restrict__ m1,
+                                                             const float* __restrict__ m2,
+                                                             const float* __restrict__ gmask, const int* __restrict__ arg,
+                                                             const double* __restrict__ cov,
+                                                             const double* __restrict__ abar_d, int B, int P,
+                                                             float* __restrict__ dW, const float* __restrict__ bn_dh,
+                                                             const float* __restrict__ bn_y,
+                                                             const float* __restrict__ bn_mean,
+                                                             const float* __restrict__ bn_rstd,
+                                                             const float* __restrict__ bn_gamma,
+                                                             const float* __restrict__ bn_beta, int rows_per_block,
+                                                             double* __restrict__ bn_part) {
+    if (blockIdx.x < C3 / 2)
+        conv3_wgrad_block(h, W3, gamma, rstd, m1, m2, gmask, arg, cov, abar_d, B, P, dW, blockIdx.x);
+    else
+        bn2_bwd_sums_block(bn_dh, bn_y, bn_mean, bn_rstd, bn_gamma, bn_beta, B * P, rows_per_block, bn_part,
+                           blockIdx.x - C3 / 2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1410,7 +1480,8 @@ hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const 
                        const float* dpooled,
                        const float* pooled, const int* arg, const float* mean, const float* rstd, int B, int P,
                        int relu_out, const Conv3Ws& w, float* m1, float* m2, float* dW3, float* db3_zero, float* dgamma,
-                       float* dbeta, float* dh2, hipStream_t s) {
+                       float* dbeta, float* dh2, hipStream_t s, const float* bn2_y, const float* bn2_mean,
+                       const float* bn2_rstd, const float* bn2_gamma, const float* bn2_beta, double* bn2_part) {
     const int M = B * P;
     hipLaunchKernelGGL(k_conv3_bwd_reduce, dim3(C3 / 16), dim3(256), 0, s, h2, W3, b3, gamma, beta, mean, rstd, dpooled,
                        pooled, arg, B, P, relu_out, w.gmask, m1, m2, dgamma, dbeta, db3_zero);
@@ -1420,8 +1491,14 @@ hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_conv3_sparse_dgrad, dim3(B), dim3(1024), 0, s, W3, gamma, rstd, (const float*)w.gmask, arg, P,
                        dh2);
-    hipLaunchKernelGGL(k_conv3_wgrad, dim3(C3), dim3(128), 0, s, h2, W3, gamma, rstd, (const float*)m1, (const float*)m2,
-                       (const float*)w.gmask, arg, (const double*)w.cov, (const double*)w.abar_d, B, P, dW3);
+    // bn2_part given: the launch also leaves the partial column sums of the backward of the BatchNorm in front of
+    // conv3 there ([t_colreduce_blocks(M)][2][128] doubles, for the finalize step of t_bn_bwd)
+    if (bn2_part != nullptr && (!bn2_y || !bn2_mean || !bn2_rstd || !bn2_gamma || !bn2_beta)) return hipErrorInvalidValue;
+    const int sum_blocks = bn2_part != nullptr ? t_colreduce_blocks(M) : 0;
+    hipLaunchKernelGGL(k_conv3_wgrad_bn2sums, dim3(C3 / 2 + sum_blocks), dim3(256), 0, s, h2, W3, gamma, rstd,
+                       (const float*)m1, (const float*)m2, (const float*)w.gmask, arg, (const double*)w.cov,
+                       (const double*)w.abar_d, B, P, dW3, (const float*)dh2, bn2_y, bn2_mean, bn2_rstd, bn2_gamma, bn2_beta,
+                       t_colreduce_rows(M), bn2_part);
     return hipGetLastError();
 }
 
