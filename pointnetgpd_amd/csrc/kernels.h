@@ -216,10 +216,12 @@ hipError_t launch_conv2_bwd_fused(float* dh2, const float* y2, const float* mean
 hipError_t launch_conv12_fwd(const float* X3, const float* W1, const float* b1, const float* mean1, const float* rstd1,
                              const float* gamma1, const float* beta1, const float* W2, const float* b2, float* h1,
                              float* y2, int M, double* stat_rec, hipStream_t s);
-hipError_t t_conv1_bwd_from_sums(const float* dh1, const float* X3, const float* W1, const float* b1, const float* mean,
-                                 const float* rstd, const float* gamma, const float* beta, int M, double* part, int nblk,
-                                 float* m1, float* m2, float* dgamma, float* dbeta, float* dbias_zero, float* dW1,
-                                 float* dX3, hipStream_t s);
+// conv2's weight gradient and conv1's whole backward behind launch_conv2_bwd_fused, three launches (train.hip)
+hipError_t t_conv2_wgrad_conv1_bwd(const float* dy2, const float* h1, float* tn_part, float* dW2, const float* dh1,
+                                   const float* X3, const float* W1, const float* b1, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta, int M, double* part, int nblk,
+                                   float* m1, float* m2, float* dgamma, float* dbeta, float* dbias_zero, float* dW1,
+                                   float* dX3, hipStream_t s);
 
 // conv3 + BatchNorm (batch statistics) + max over points without the [M,1024] activation (train_conv3.hip)
 struct Conv3Ws {

@@ -288,11 +288,11 @@ __global__ __launch_bounds__(256) void k_stats_finalize(const double* __restrict
 }
 
 // m1 = s1/M, m2 = s2/M; dgamma = s2, dbeta = s1; the bias of the layer in front of the BatchNorm gets its exact 0
-__global__ __launch_bounds__(256) void k_bnbwd_finalize(const double* __restrict__ part, int nblk, int M, int C,
-                                                        float* __restrict__ m1, float* __restrict__ m2,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                        float* __restrict__ dbias_zero) {
-    const int c = blockIdx.x * FIN_COLS + (threadIdx.x & (FIN_COLS - 1)), rl = threadIdx.x / FIN_COLS;
+__device__ __forceinline__ void bnbwd_finalize_block(const double* __restrict__ part, int nblk, int M, int C,
+                                                     float* __restrict__ m1, float* __restrict__ m2,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dbias_zero, int blk) {
+    const int c = blk * FIN_COLS + (threadIdx.x & (FIN_COLS - 1)), rl = threadIdx.x / FIN_COLS;
     double s1, s2;
     sum_partials2(part, nblk, C, c, rl, s1, s2);
     if (rl != 0 || c >= C) return;
@@ -301,6 +301,13 @@ __global__ __launch_bounds__(256) void k_bnbwd_finalize(const double* __restrict
     dgamma[c] = (float)s2;
     dbeta[c] = (float)s1;
     if (dbias_zero != nullptr) dbias_zero[c] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_bnbwd_finalize(const double* __restrict__ part, int nblk, int M, int C,
+                                                        float* __restrict__ m1, float* __restrict__ m2,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        float* __restrict__ dbias_zero) {
+    bnbwd_finalize_block(part, nblk, M, C, m1, m2, dgamma, dbeta, dbias_zero, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -525,12 +532,12 @@ __global__ __launch_bounds__(256) void k_conv1_bn_bwd_dense(float* __restrict__ 
 // never stored - partial sums of dW1[c,j] = sum_m dy1[m,c] X3[m,j] (part [gridDim.x][64*3] doubles, for
 // k_reduce_double) and, when dX3 is given, dX3[m,j] = sum_c dy1[m,c] W1[c,j].
 // block = 16 column quads x 16 row lanes over 256 rows.
-__global__ __launch_bounds__(256) void k_conv1_bwd_all(const float* __restrict__ dh, const float* __restrict__ X3,
-                                                       const float* __restrict__ W1, const float* __restrict__ b1,
-                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ m1, const float* __restrict__ m2, int M,
-                                                       double* __restrict__ part, float* __restrict__ dX3) {
+__device__ __forceinline__ void conv1_bwd_all_block(const float* __restrict__ dh, const float* __restrict__ X3,
+                                                    const float* __restrict__ W1, const float* __restrict__ b1,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ m1, const float* __restrict__ m2, int M,
+                                                    double* __restrict__ part, float* __restrict__ dX3, int blk) {
     __shared__ float sw[16][64][3];
     const int cq = threadIdx.x & 15, col = cq * 4, rl = threadIdx.x >> 4;
     float wq[4][3], bq[4], mu[4], rs[4], gr[4], a1[4], a2[4], ga[4], be[4], acc[4][3];
@@ -549,7 +556,7 @@ __global__ __launch_bounds__(256) void k_conv1_bwd_all(const float* __restrict__
         a2[e] = m2[col + e];
         acc[e][0] = acc[e][1] = acc[e][2] = 0.f;
     }
-    const int r0 = blockIdx.x * 256;
+    const int r0 = blk * 256;
 #pragma unroll 4
     for (int j = 0; j < 16; ++j) {
         const int r = r0 + rl + 16 * j;
@@ -594,8 +601,27 @@ __global__ __launch_bounds__(256) void k_conv1_bwd_all(const float* __restrict__
         const int c = threadIdx.x / 3, j = threadIdx.x - 3 * c;
         double t = 0.0;
         for (int k = 0; k < 16; ++k) t += (double)sw[k][c][j];      // fixed order: reproducible
-        part[(size_t)blockIdx.x * 192 + threadIdx.x] = t;
+        part[(size_t)blk * 192 + threadIdx.x] = t;
     }
+}
+
+__device__ __forceinline__ void reduce_chunks_block(const float* __restrict__ part, int chunks, size_t n,
+                                                    float* __restrict__ out, int blk);      // defined below
+
+// workgroups [0, n_rows) as above; the rest add up the chunks of another product's partial sums (reduce_chunks_block:
+// the weight gradient of the layer behind, which this pass does not depend on) - one launch instead of two
+__global__ __launch_bounds__(256) void k_conv1_bwd_all(const float* __restrict__ dh, const float* __restrict__ X3,
+                                                       const float* __restrict__ W1, const float* __restrict__ b1,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ m1, const float* __restrict__ m2, int M,
+                                                       double* __restrict__ part, float* __restrict__ dX3, int n_rows,
+                                                       const float* __restrict__ chunk_part, int chunks, size_t chunk_n,
+                                                       float* __restrict__ chunk_out) {
+    if ((int)blockIdx.x < n_rows)
+        conv1_bwd_all_block(dh, X3, W1, b1, mean, rstd, gamma, beta, m1, m2, M, part, dX3, blockIdx.x);
+    else
+        reduce_chunks_block(chunk_part, chunks, chunk_n, chunk_out, blockIdx.x - n_rows);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -714,6 +740,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     gemm_tn_block(dY, Hm, part, M, N, K, rows_per_chunk, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// The weight-gradient product with the finalize step of an independent BatchNorm backward riding along: workgroups
+// [0, n_fin) are k_bnbwd_finalize's, the rest the product's grid (K/64, N/64, chunks).
+__global__ __launch_bounds__(256) void gemm_tn_finalize_kernel(const float* __restrict__ dY, const float* __restrict__ Hm,
+                                                               float* __restrict__ tn_out, int M, int N, int K,
+                                                               int rows_per_chunk, int n_fin,
+                                                               const double* __restrict__ fin_part, int fin_nblk,
+                                                               int fin_C, float* __restrict__ m1, float* __restrict__ m2,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dbias_zero) {
+    int b = blockIdx.x;
+    if (b < n_fin) {
+        bnbwd_finalize_block(fin_part, fin_nblk, M, fin_C, m1, m2, dgamma, dbeta, dbias_zero, b);
+    } else {
+        b -= n_fin;
+        const int kx = K / 64;
+        gemm_tn_block(dY, Hm, tn_out, M, N, K, rows_per_chunk, b % kx, (b / kx) % (N / 64), b / (kx * (N / 64)));
+    }
+}
+
 // Both products of a linear layer's backward in one launch - they share dY and nothing else, and at a few hundred
 // rows neither fills the chip: workgroups [0, n_tn) take the weight-gradient product's grid (K/64, N/64, chunks),
 // the rest the input-gradient product's (K/64, ceil(M/64), slices).
@@ -736,11 +781,11 @@ __global__ __launch_bounds__(256) void gemm_tn_nn_kernel(const float* __restrict
 
 // out[i] = sum over chunks of part[chunk][i].  block = 16 elements x 16 chunk lanes: a lane sums every 16th
 // chunk, the lane sums are added in a fixed order (reproducible).
-__global__ __launch_bounds__(256) void k_reduce_chunks(const float* __restrict__ part, int chunks, size_t n,
-                                                       float* __restrict__ out) {
+__device__ __forceinline__ void reduce_chunks_block(const float* __restrict__ part, int chunks, size_t n,
+                                                    float* __restrict__ out, int blk) {
     __shared__ float sh[16][16];
     const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const size_t i = (size_t)blockIdx.x * 16 + el;
+    const size_t i = (size_t)blk * 16 + el;
     float s = 0.f;
     if (i < n)
 #pragma unroll 4
@@ -751,6 +796,11 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const float* __restrict__
     s = 0.f;
     for (int k = 0; k < 16; ++k) s += sh[k][el];
     out[i] = s;
+}
+
+__global__ __launch_bounds__(256) void k_reduce_chunks(const float* __restrict__ part, int chunks, size_t n,
+                                                       float* __restrict__ out) {
+    reduce_chunks_block(part, chunks, n, out, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1098,18 +1148,25 @@ hipError_t t_bn_bwd_finalize(const double* part, int nblk, int M, int C, float* 
                        dbias_zero);
     return hipGetLastError();
 }
-// the second half of t_bn_bwd for conv1's BatchNorm with the column sums already in part ([nblk][2][64] doubles),
-// followed by t_conv1_bwd, without storing dy1: dW1 and (dX3 != nullptr) dX3.  part is reused for the partial sums
-// of dW1 and must hold t_red_blocks(M) * 192 doubles.
-hipError_t t_conv1_bwd_from_sums(const float* dh1, const float* X3, const float* W1, const float* b1, const float* mean,
-                                 const float* rstd, const float* gamma, const float* beta, int M, double* part, int nblk,
-                                 float* m1, float* m2, float* dgamma, float* dbeta, float* dbias_zero, float* dW1,
-                                 float* dX3, hipStream_t s) {
-    hipLaunchKernelGGL(k_bnbwd_finalize, grid1(64, FIN_COLS), dim3(256), 0, s, (const double*)part, nblk, M, 64, m1, m2,
-                       dgamma, dbeta, dbias_zero);
+// What follows the fused backward pass of conv2 (train_bwd2.hip) in three launches: (1) the weight gradient of conv2,
+// dW2[128,64] = dy2^T h1 as partial products, with the finalize step of conv1's BatchNorm backward (column sums in
+// part, [nblk][2][64] doubles) riding along; (2) conv1's backward straight from dh1 - dW1 partial sums into part,
+// which must hold t_red_blocks(M) * 192 doubles, and dX3 if wanted - with the reduction of dW2's partial products
+// riding along; (3) the reduction of dW1's partial sums.
+hipError_t t_conv2_wgrad_conv1_bwd(const float* dy2, const float* h1, float* tn_part, float* dW2, const float* dh1,
+                                   const float* X3, const float* W1, const float* b1, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta, int M, double* part, int nblk,
+                                   float* m1, float* m2, float* dgamma, float* dbeta, float* dbias_zero, float* dW1,
+                                   float* dX3, hipStream_t s) {
+    const int chunks = t_tn_chunks(M);
+    const int n_tn = (C1 / 64) * (C2 / 64) * chunks, n_fin = 64 / FIN_COLS;
+    hipLaunchKernelGGL(gemm_tn_finalize_kernel, dim3(n_fin + n_tn), dim3(256), 0, s, dy2, h1, chunks == 1 ? dW2 : tn_part, M,
+                       C2, C1, TN_ROWS_PER_CHUNK, n_fin, (const double*)part, nblk, 64, m1, m2, dgamma, dbeta, dbias_zero);
     const int wblk = t_red_blocks(M);
-    hipLaunchKernelGGL(k_conv1_bwd_all, dim3(wblk), dim3(256), 0, s, dh1, X3, W1, b1, mean, rstd, gamma, beta,
-                       (const float*)m1, (const float*)m2, M, part, dX3);
+    const size_t nw = (size_t)C2 * C1;
+    const int rblk = chunks > 1 ? (int)((nw + 15) / 16) : 0;
+    hipLaunchKernelGGL(k_conv1_bwd_all, dim3(wblk + rblk), dim3(256), 0, s, dh1, X3, W1, b1, mean, rstd, gamma, beta,
+                       (const float*)m1, (const float*)m2, M, part, dX3, wblk, (const float*)tn_part, chunks, nw, dW2);
     hipLaunchKernelGGL(k_reduce_double, grid1(192, FIN_COLS), dim3(256), 0, s, (const double*)part, wblk, 192, dW1);
     return hipGetLastError();
 }

@@ -244,13 +244,13 @@ int bwd_stack(StackWs& S, const float* const* p, float* const* g, int u1, const 
                                               cslot(p, u1, PNGPD_F_WEIGHT), cslot(p, u1, PNGPD_F_BIAS), S.mean[0],
                                               S.rstd[0], cslot(p, u1, PNGPD_F_BN_WEIGHT), cslot(p, u1, PNGPD_F_BN_BIAS),
                                               W.part, s));
-        HIP_TRY(pngpd::t_gemm_tn(S.dh2, S.h1, W.tn_part, slot(g, u1 + 1, PNGPD_F_WEIGHT), M, C2, C1, s));
-        HIP_TRY(pngpd::t_conv1_bwd_from_sums(S.dh1, S.X3, cslot(p, u1, PNGPD_F_WEIGHT), cslot(p, u1, PNGPD_F_BIAS),
-                                             S.mean[0], S.rstd[0], cslot(p, u1, PNGPD_F_BN_WEIGHT),
-                                             cslot(p, u1, PNGPD_F_BN_BIAS), M, W.part, pngpd::tall_gemm_blocks(M), W.m1,
-                                             W.m2, slot(g, u1, PNGPD_F_BN_WEIGHT), slot(g, u1, PNGPD_F_BN_BIAS),
-                                             slot(g, u1, PNGPD_F_BIAS), slot(g, u1, PNGPD_F_WEIGHT),
-                                             need_dX3 ? S.dX3 : nullptr, s));
+        HIP_TRY(pngpd::t_conv2_wgrad_conv1_bwd(S.dh2, S.h1, W.tn_part, slot(g, u1 + 1, PNGPD_F_WEIGHT), S.dh1, S.X3,
+                                               cslot(p, u1, PNGPD_F_WEIGHT), cslot(p, u1, PNGPD_F_BIAS), S.mean[0],
+                                               S.rstd[0], cslot(p, u1, PNGPD_F_BN_WEIGHT), cslot(p, u1, PNGPD_F_BN_BIAS),
+                                               M, W.part, pngpd::tall_gemm_blocks(M), W.m1, W.m2,
+                                               slot(g, u1, PNGPD_F_BN_WEIGHT), slot(g, u1, PNGPD_F_BN_BIAS),
+                                               slot(g, u1, PNGPD_F_BIAS), slot(g, u1, PNGPD_F_WEIGHT),
+                                               need_dX3 ? S.dX3 : nullptr, s));
         return PNGPD_OK;
     }
     HIP_TRY(pngpd::t_bn_bwd(S.dh2, S.h2, S.y2, S.mean[1], S.rstd[1], cslot(p, u1 + 1, PNGPD_F_BN_WEIGHT), M, C2, W.part,
