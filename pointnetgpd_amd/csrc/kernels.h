@@ -199,13 +199,11 @@ hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean
                     float* dbeta, float* dbias_zero, hipStream_t s,
                     const float* conv1_x3 = nullptr, const float* conv1_w = nullptr, const float* conv1_b = nullptr,
                     const float* beta = nullptr);
-// t_bn_bwd of the two per-point layers in front of conv3, cut differently (train_bwd2.hip): sums of BatchNorm 2 ->
-// one pass that turns dh2 into dy2 in place, multiplies it with W2 into dh1 and leaves the partial column sums of
-// BatchNorm 1's backward in part ([tall_gemm_blocks(M)][2][64] doubles) -> the rest of the stack's backward (dW1, dX3)
-// straight from dh1, without storing dy1
-hipError_t t_bn_bwd_sums(const float* dh, const float* y, const float* mean, const float* rstd, const float* gamma,
-                         const float* beta, int M, int C, double* part, float* m1, float* m2, float* dgamma,
-                         float* dbeta, float* dbias_zero, hipStream_t s);
+// t_bn_bwd of the two per-point layers in front of conv3, cut differently (train_bwd2.hip): sums of BatchNorm 2 (by
+// t_conv3_bwd's last launch, finalized by t_bn_bwd_finalize) -> one pass that turns dh2 into dy2 in place, multiplies
+// it with W2 into dh1 and leaves the partial column sums of BatchNorm 1's backward in part
+// ([tall_gemm_blocks(M)][2][64] doubles) -> the rest of the stack's backward (dW2, dW1, dX3) by
+// t_conv2_wgrad_conv1_bwd, straight from dy2 and dh1, without storing dy1
 hipError_t launch_conv2_bwd_fused(float* dh2, const float* y2, const float* mean2, const float* rstd2,
                                   const float* gamma2, const float* beta2, const float* m1, const float* m2,
                                   const float* W2, float* dh1, int M, const float* X3, const float* W1, const float* b1,
@@ -255,8 +253,6 @@ hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const 
 // the finalize step of t_bn_bwd alone: partial column sums ([nblk][2][C] doubles) -> m1, m2, dgamma, dbeta
 hipError_t t_bn_bwd_finalize(const double* part, int nblk, int M, int C, float* m1, float* m2, float* dgamma,
                              float* dbeta, float* dbias_zero, hipStream_t s);
-hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s,
-                     float* splitk_part = nullptr);
 hipError_t t_gemm_tn(const float* dY, const float* Hm, float* part, float* dW, int M, int N, int K, hipStream_t s);
 // both of the above for one linear layer [N out, K in] in one launch: dW[N,K] = dY^T Hm, dX[M,K] = dY W
 hipError_t t_gemm_tn_nn(const float* dY, const float* Hm, float* tn_part, float* dW, const float* W, float* dX, int M,

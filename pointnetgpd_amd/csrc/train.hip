@@ -5,8 +5,9 @@
 // for the per-point layers and M = B for the fully connected layers.  All matrix products run on
 // the exact-f32 MFMA (v_mfma_f32_32x32x2_f32) in three shapes:
 //     NT  Y[M,N]  = X[M,K]  W[N,K]^T + b      forward            (fc_f32_kernel in fc.hip)
-//     NN  dX[M,K] = dY[M,N] W[N,K]            input gradient     (gemm_nn_kernel)
-//     TN  dW[N,K] = dY[M,N]^T H[M,K]          weight gradient    (gemm_tn_kernel, split over M)
+//     NN  dX[M,K] = dY[M,N] W[N,K]            input gradient     (gemm_nn_block)
+//     TN  dW[N,K] = dY[M,N]^T H[M,K]          weight gradient    (gemm_tn_block, split over M)
+// (the two of one layer share a launch, gemm_tn_nn_kernel)
 // BatchNorm uses batch statistics over the M rows (biased variance for the normalisation,
 // unbiased for running_var, momentum 0.1, eps 1e-5: torch.nn.BatchNorm1d defaults, which the
 // reference keeps, model/pointnet.py:21-25).  Its backward is
@@ -679,12 +680,6 @@ __device__ __forceinline__ void gemm_nn_block(const float* __restrict__ dY, cons
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ dY, const float* __restrict__ W,
-                                                      float* __restrict__ dX, int M, int N, int Kout,
-                                                      float* __restrict__ part) {
-    gemm_nn_block(dY, W, dX, M, N, Kout, part, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
-}
-
 // partial dW[chunk][N,K] = dY[rows of chunk, N]^T H[rows of chunk, K];  N % 64 == 0, K % 64 == 0
 // grid (K/64, N/64, chunks); rows_per_chunk % 32 == 0
 __device__ __forceinline__ void gemm_tn_block(const float* __restrict__ dY, const float* __restrict__ Hm,
@@ -1128,20 +1123,6 @@ hipError_t t_bn_bwd(float* dh, const float* h, const float* y, const float* mean
                            (size_t)M * C / 4, C, beta);
     return hipGetLastError();
 }
-// the first half of t_bn_bwd for a per-point layer behind a ReLU: column sums of the masked gradient (mask from the
-// recomputed pre-activation) and what follows from them (m1, m2, dgamma, dbeta); dh is left as it is
-hipError_t t_bn_bwd_sums(const float* dh, const float* y, const float* mean, const float* rstd, const float* gamma,
-                         const float* beta, int M, int C, double* part, float* m1, float* m2, float* dgamma,
-                         float* dbeta, float* dbias_zero, hipStream_t s) {
-    if (!beta || C % 4 != 0) return hipErrorInvalidValue;
-    const int nblk = t_colreduce_blocks(M);
-    hipLaunchKernelGGL(k_colreduce, dim3(colreduce_grid_x(C), nblk), dim3(256), 0, s, dh, (const float*)nullptr, y, mean,
-                       rstd, M, C, 1, t_colreduce_rows(M), part, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, gamma, beta);
-    hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta,
-                       dbias_zero);
-    return hipGetLastError();
-}
 hipError_t t_bn_bwd_finalize(const double* part, int nblk, int M, int C, float* m1, float* m2, float* dgamma,
                              float* dbeta, float* dbias_zero, hipStream_t s) {
     hipLaunchKernelGGL(k_bnbwd_finalize, grid1(C, FIN_COLS), dim3(256), 0, s, part, nblk, M, C, m1, m2, dgamma, dbeta,
@@ -1170,21 +1151,9 @@ hipError_t t_conv2_wgrad_conv1_bwd(const float* dy2, const float* h1, float* tn_
     hipLaunchKernelGGL(k_reduce_double, grid1(192, FIN_COLS), dim3(256), 0, s, (const double*)part, wblk, 192, dW1);
     return hipGetLastError();
 }
-hipError_t t_gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kout, hipStream_t s,
-                     float* splitk_part) {
-    if (Kout % 64 != 0 || N % 32 != 0) return hipErrorInvalidValue;
-    dim3 grid(Kout / 64, (M + 63) / 64);
-    int ks = splitk_part != nullptr ? splitk_factor((int)(grid.x * grid.y), N / GB_K) : 1;
-    if ((size_t)ks * M * Kout > SPLITK_PART_FLOATS) ks = 1;
-    grid.z = ks;
-    hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(256), 0, s, dY, W, dX, M, N, Kout, ks > 1 ? splitk_part : (float*)nullptr);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || ks == 1) return e;
-    return launch_splitk_reduce(splitk_part, ks, M, Kout, nullptr, 0, dX, s);
-}
 int t_tn_chunks(int M) { return (M + TN_ROWS_PER_CHUNK - 1) / TN_ROWS_PER_CHUNK; }
 
-// t_gemm_tn(dY, Hm -> dW) and t_gemm_nn(dY, W -> dX) of one linear layer [N out, K in] as one launch (plus the
+// dW[N,K] = dY^T Hm (as t_gemm_tn) and dX[M,K] = dY W of one linear layer [N out, K in] as one launch (plus the
 // reductions of their partial products, if any)
 hipError_t t_gemm_tn_nn(const float* dY, const float* Hm, float* tn_part, float* dW, const float* W, float* dX, int M,
                         int N, int K, hipStream_t s, float* splitk_part) {
