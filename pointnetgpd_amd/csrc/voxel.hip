@@ -251,59 +251,18 @@ __global__ __launch_bounds__(VX_THREADS) void k_vox_count(const unsigned int* bi
     }
 }
 
-// exclusive scan of blocksum[0..nb) in place; blocksum[nb] = total; *count = total.  One pass: a thread owns a run of
-// consecutive entries (in registers), runs are scanned by wave shuffles, the 16 wave totals summed from LDS.  (A
-// Hillis-Steele scan of 1024 entries at a time, twenty barriers per 1024, took 8.3 us for the 3,815 entries of n = 500.
-// Folding this scan into the count kernel - the block that finishes last scans - was measured as well: 3,815 blocks
-// bumping ONE device-scope counter serialise at the memory side, 0.083 -> 0.123 ms per call.)
-constexpr int VX_SCAN_THREADS = 1024, VX_SCAN_RUN = 8;
-__global__ __launch_bounds__(VX_SCAN_THREADS) void k_vox_scan(unsigned int* blocksum, int nb, int* count) {
-    __shared__ unsigned int s_wave[VX_SCAN_THREADS / 64];
-    __shared__ unsigned int s_carry;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nb; base += VX_SCAN_THREADS * VX_SCAN_RUN) {
-        const int i0 = base + threadIdx.x * VX_SCAN_RUN;
-        unsigned int v[VX_SCAN_RUN], c = 0;
-#pragma unroll
-        for (int j = 0; j < VX_SCAN_RUN; ++j) {
-            v[j] = i0 + j < nb ? blocksum[i0 + j] : 0u;
-            c += v[j];
-        }
-        unsigned int inc = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int t = __shfl_up(inc, off);
-            if (lane >= off) inc += t;
-        }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        unsigned int before = s_carry;
-        for (int k = 0; k < wave; ++k) before += s_wave[k];
-        unsigned int run = before + inc - c;
-#pragma unroll
-        for (int j = 0; j < VX_SCAN_RUN; ++j) {
-            if (i0 + j < nb) blocksum[i0 + j] = run;
-            run += v[j];
-        }
-        __syncthreads();
-        if (threadIdx.x == VX_SCAN_THREADS - 1) s_carry = run;     // the last thread's run ends the chunk
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        blocksum[nb] = s_carry;
-        *count = (int)s_carry;
-    }
-}
-
 struct __attribute__((packed, aligned(4))) VoxRow {
     float x, y, z;
 };
 
+// Rows of the set bits in ascending bit order.  A workgroup's first output row is the number of set bits in the
+// workgroups before it, which it adds up from their counts itself (blocksum, 3,815 entries at n = 500: on average
+// half of them, eight loads per thread - a scan launch between the count and this pass took 5 us and a launch gap; the
+// scan folded into the count kernel, the block that finishes last scanning, was slower still: thousands of blocks
+// bumping ONE device-scope counter serialise at the memory side).  The last workgroup also stores the total.
 __global__ __launch_bounds__(VX_THREADS) void k_vox_emit(const unsigned int* bitmap, size_t words,
                                                          const unsigned int* blocksum, const float* mid, int n,
-                                                         float* out, long long capacity) {
+                                                         float* out, long long capacity, int* count) {
     // each thread owns 4 consecutive words: ascending bit order is preserved
     constexpr int WPT = VX_WORDS_PER_BLOCK / VX_THREADS;
     const size_t base = (size_t)blockIdx.x * VX_WORDS_PER_BLOCK + (size_t)threadIdx.x * WPT;
@@ -313,8 +272,11 @@ __global__ __launch_bounds__(VX_THREADS) void k_vox_emit(const unsigned int* bit
         w[j] = base + j < words ? bitmap[base + j] : 0u;
         c += __popc(w[j]);
     }
-    // exclusive prefix of c over the block: shuffles inside a wave, one barrier for the four wave totals
-    __shared__ unsigned int s_wave[VX_THREADS / 64];
+    unsigned int pre = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += VX_THREADS) pre += blocksum[i];
+    // exclusive prefix of c over the block: shuffles inside a wave, one barrier for the wave totals (and for the sums
+    // of the earlier workgroups' counts)
+    __shared__ unsigned int s_wave[VX_THREADS / 64], s_pre[VX_THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned int inc = c;
 #pragma unroll
@@ -322,11 +284,19 @@ __global__ __launch_bounds__(VX_THREADS) void k_vox_emit(const unsigned int* bit
         const unsigned int t = __shfl_up(inc, off);
         if (lane >= off) inc += t;
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off);
     if (lane == 63) s_wave[wave] = inc;
+    if (lane == 0) s_pre[wave] = pre;
     __syncthreads();
-    unsigned int before = 0;
-    for (int k = 0; k < wave; ++k) before += s_wave[k];
-    long long pos = (long long)blocksum[blockIdx.x] + before + inc - c;
+    unsigned int before = 0, first = 0, total = 0;
+    for (int k = 0; k < VX_THREADS / 64; ++k) {
+        if (k < wave) before += s_wave[k];
+        first += s_pre[k];
+        total += s_wave[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count = (int)(first + total);
+    long long pos = (long long)first + before + inc - c;
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
         unsigned int bits = w[j];
@@ -381,8 +351,8 @@ hipError_t launch_voxel_unique(const float* pts, int S, int n, int f32_edges, vo
     hipLaunchKernelGGL(k_vox_mark, dim3(mark_blocks), dim3(VX_THREADS), (size_t)3 * n * 8, s, pts, S, w.partial, red_blocks, n,
                        f32_edges, w.mid, w.bitmap);
     hipLaunchKernelGGL(k_vox_count, dim3(nb), dim3(VX_THREADS), 0, s, w.bitmap, words, w.blocksum);
-    hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(VX_SCAN_THREADS), 0, s, w.blocksum, nb, count);
-    hipLaunchKernelGGL(k_vox_emit, dim3(nb), dim3(VX_THREADS), 0, s, w.bitmap, words, w.blocksum, w.mid, n, out, capacity);
+    hipLaunchKernelGGL(k_vox_emit, dim3(nb), dim3(VX_THREADS), 0, s, w.bitmap, words, w.blocksum, w.mid, n, out, capacity,
+                       count);
     return hipGetLastError();
 }
 
