@@ -209,6 +209,8 @@ hipError_t launch_conv2_bwd_fused(float* dh2, const float* y2, const float* mean
                                   const float* W2, float* dh1, int M, const float* X3, const float* W1, const float* b1,
                                   const float* mean1, const float* rstd1, const float* gamma1, const float* beta1,
                                   double* part, hipStream_t s);
+// Y[M,128] = X[M,128] G + ub, G [128][128] (row = input channel), products of two bfloat16 pieces per operand
+hipError_t launch_dense_dgrad_x3(const float* X, const float* G, const float* ub, float* Y, int M, hipStream_t s);
 // forward of conv1 / bn1 / relu / conv2 in one pass (statistics of bn1 given): h1, y2 and the column-statistic records
 // of y2 ([tall_gemm_blocks(M)][128][3] doubles, for t_stats_from_records)
 hipError_t launch_conv12_fwd(const float* X3, const float* W1, const float* b1, const float* mean1, const float* rstd1,

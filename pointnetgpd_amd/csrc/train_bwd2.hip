@@ -386,6 +386,124 @@ hipError_t launch_conv12_fwd(const float* X3, const float* W1, const float* b1, 
     return hipGetLastError();
 }
 
+// Y[M,128] = X[M,128] G + ub (G [128][128], row k = input channel) with float32-grade products on the bfloat16 matrix
+// pipe: every operand is two bfloat16 pieces (hi = bf16(v), lo = bf16(v - hi): 16 significand bits), a product three
+// MFMAs accumulating in float32 (lo.hi, hi.lo, hi.hi - the dropped lo.lo and the representation remainders are below
+// 2^-16 of the product).  This is the dense part of conv3's input gradient (h2 times the 128x128 matrix that the
+// BatchNorm statistics contribute), 6.3 GFLOP per call that take 40 us on the float32 MFMA and 7.5 us this way, so
+// that the pass is bound by its rows (98 MB in, 98 MB out) instead.  Structure as conv2_bwd_fused_kernel: persistent
+// workgroups, G resident in LDS as B fragments of v_mfma_f32_32x32x16_bf16 (two planes), a tile of 128 rows in two
+// phases of 64 summed terms, the next phase's floats in flight during the MFMAs.  Lane (r, h) owns row r of its wave's
+// 32 and, per 16-term step, the 8 consecutive floats [16 ks + 8 h, + 8).
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 dg_bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 dg_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float dg_f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int dg_u32x4;
+constexpr int DG_PLANE_BYTES = 4 * 8 * 64 * 16;       // [column tile 4][step 8][lane 64] x 16 B
+constexpr size_t DG_LDS_BYTES = 2 * DG_PLANE_BYTES;
+
+// hi and lo pieces of eight floats as A/B fragment registers
+__device__ __forceinline__ void dg_split8(const float4& v0, const float4& v1, dg_bf16x8& hi, dg_bf16x8& lo) {
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    dg_u32x4 h, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(dg_f32x2{x[2 * q], x[2 * q + 1]}, dg_bf16x2));
+        const float r0 = x[2 * q] - __builtin_bit_cast(float, hp << 16);
+        const float r1 = x[2 * q + 1] - __builtin_bit_cast(float, hp & 0xffff0000u);
+        h[q] = hp;
+        l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(dg_f32x2{r0, r1}, dg_bf16x2));
+    }
+    hi = __builtin_bit_cast(dg_bf16x8, h);
+    lo = __builtin_bit_cast(dg_bf16x8, l);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void dense_dgrad_x3_kernel(const float* __restrict__ X, const float* __restrict__ G,
+                                                                const float* __restrict__ ub, float* __restrict__ Y,
+                                                                int M) {
+    extern __shared__ __attribute__((aligned(16))) char dg_smem[];
+    char* sBh = dg_smem;
+    char* sBl = dg_smem + DG_PLANE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (int idx = tid; idx < 128 * 128; idx += 256) {
+        const int k = idx >> 7, n = idx & 127;
+        const float v = G[idx];
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
+        const int off = ((((n >> 5) * 8 + (k >> 4)) * 64 + (n & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7)) * 2;
+        *(__bf16*)(sBh + off) = hi;
+        *(__bf16*)(sBl + off) = lo;
+    }
+    __syncthreads();
+    float bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv[t] = ub[32 * t + r];
+
+    const int tiles = (M + 127) / 128;
+    float4 a[8];
+    auto load_phase = [&](int tile, int p) {
+        int row = tile * 128 + wave * 32 + r;
+        row = row < M ? row : M - 1;
+        const float* src = X + (size_t)row * 128 + 64 * p + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            a[2 * ks] = *(const float4*)(src + 16 * ks);
+            a[2 * ks + 1] = *(const float4*)(src + 16 * ks + 4);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < tiles) load_phase(tile, 0);
+    for (; tile < tiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x16{0};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            dg_bf16x8 ah[4], al[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dg_split8(a[2 * ks], a[2 * ks + 1], ah[ks], al[ks]);
+            if (p == 0)
+                load_phase(tile, 1);
+            else if (next < tiles)
+                load_phase(next, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int off = ((t * 8 + 4 * p + ks) * 64 + lane) * 16;
+                    const dg_bf16x8 bh = *(const dg_bf16x8*)(sBh + off);
+                    const dg_bf16x8 bl = *(const dg_bf16x8*)(sBl + off);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int row0 = tile * 128 + wave * 32 + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + (i & 3) + 8 * (i >> 2);
+                if (row < M) Y[(size_t)row * 128 + 32 * t + r] = acc[t][i] + bv[t];
+            }
+    }
+}
+
+hipError_t launch_dense_dgrad_x3(const float* X, const float* G, const float* ub, float* Y, int M, hipStream_t s) {
+    if (!X || !G || !ub || !Y || M < 1) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void*)dense_dgrad_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)DG_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dense_dgrad_x3_kernel, dim3(tall_gemm_blocks(M)), dim3(256), DG_LDS_BYTES, s, X, G, ub, Y, M);
+    return hipGetLastError();
+}
+
 // dh2 [M,128]: in dL/dh2 (before the ReLU mask), out dL/dy2.  dh1 [M,64]: dL/dh1 (before conv1's ReLU mask).
 // part: [tall_gemm_blocks(M)][2][64] doubles, the partial column sums for BatchNorm 1's backward.
 hipError_t launch_conv2_bwd_fused(float* dh2, const float* y2, const float* mean2, const float* rstd2,

@@ -1487,7 +1487,11 @@ hipError_t t_conv3_bwd(const float* h2, const float* W3, const float* b3, const 
                        pooled, arg, B, P, relu_out, w.gmask, m1, m2, dgamma, dbeta, db3_zero);
     hipLaunchKernelGGL(k_conv3_bwd_G, dim3(C2 + 1), dim3(512), 0, s, W3, b3, gamma, mean, rstd, (const float*)m1,
                        (const float*)m2, w.G, w.ub);
-    hipError_t e = launch_tall_gemm(h2, w.G, 1, w.ub, dh2, M, C2, C2, 0, nullptr, s);
+    // the dense part of the input gradient, h2 G + ub: split-bfloat16 products by default, PNGPD_TRAIN_DGRAD=f32 keeps it
+    // on the float32 matrix instruction (read at every call, like the switches of t_conv3_fwd)
+    const char* dgrad_env = getenv("PNGPD_TRAIN_DGRAD");
+    hipError_t e = dgrad_env && dgrad_env[0] == 'f' ? launch_tall_gemm(h2, w.G, 1, w.ub, dh2, M, C2, C2, 0, nullptr, s)
+                                                    : launch_dense_dgrad_x3(h2, w.G, w.ub, dh2, M, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_conv3_sparse_dgrad, dim3(B), dim3(1024), 0, s, W3, gamma, rstd, (const float*)w.gmask, arg, P,
                        dh2);

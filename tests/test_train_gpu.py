@@ -611,3 +611,41 @@ def test_backward_of_the_per_point_layers_in_one_pass_agrees_with_the_kernel_per
             worst = (n, err / scale)
         assert err <= 2e-5 * scale, (n, err / scale)
     print(f"P={P} B={B}: largest difference {worst[1]:.2e} of the gradient's largest entry ({worst[0]})")
+
+
+@pytest.mark.parametrize("P,B,k,seed", [(750, 24, 2, 31), (37, 150, 3, 32)])
+def test_dense_input_gradient_on_split_bfloat16_agrees_with_the_float32_product(monkeypatch, P, B, k, seed):
+    """The dense part of conv3's input gradient (h2 times a 128x128 matrix) runs as three products of bfloat16 pieces
+    per float32 product (dense_dgrad_x3_kernel: 16 significand bits per operand); PNGPD_TRAIN_DGRAD=f32 keeps it on
+    the float32 matrix instruction.  Same state, same batch, same forward: every gradient of the two forms agrees to
+    1e-4 of its largest entry (measured: a few 1e-6)."""
+    from pointnetgpd_amd import training
+    x = torch.from_numpy(synth.candidate_points(seed, B, P, "normal")).cuda()
+    target = torch.from_numpy((synth.uniform(seed, "labels", (B,)) * k).astype(np.int64)).cuda()
+    got = {}
+    for form in ("f32", "x3"):
+        if form == "f32":
+            monkeypatch.setenv("PNGPD_TRAIN_DGRAD", "f32")
+        else:
+            monkeypatch.delenv("PNGPD_TRAIN_DGRAD", raising=False)
+        m = hip_train_model(P, k, seed, 1.3)
+        logp, trans, ws, xc = training.train_forward(m, x)
+        loss, dlogp = nll_loss(logp, target)
+        grads = {n: torch.zeros_like(p) for n, p in m.named_parameters()}
+        by_id = {id(p): grads[n] for n, p in m.named_parameters()}
+        training.train_backward(m, xc, logp, dlogp, None, ws, lambda p: by_id[id(p)])
+        torch.cuda.synchronize()
+        got[form] = {n: g.double().cpu() for n, g in grads.items()}
+    worst = ("", 0.0)
+    for n, ref in got["f32"].items():
+        g = got["x3"][n]
+        assert torch.isfinite(g).all(), n
+        scale = float(ref.abs().max())
+        err = float((g - ref).abs().max())
+        if scale < 1e-7:
+            assert err < 1e-6, (n, err)
+            continue
+        if err / scale > worst[1]:
+            worst = (n, err / scale)
+        assert err <= 1e-4 * scale, (n, err / scale)
+    print(f"P={P} B={B}: largest difference {worst[1]:.2e} of the gradient's largest entry ({worst[0]})")
