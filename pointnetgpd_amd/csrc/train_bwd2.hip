@@ -240,9 +240,16 @@ __global__ __launch_bounds__(256, 2) void conv12_fwd_kernel(const float* __restr
     float* sC1 = g_smem + G_W2_FLOATS;           // [8][64]: three weights, bias, mean, rstd, gamma, beta of layer 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    for (int i = tid; i < GK * GN; i += 256) {
-        const int n = i / GK, k = i - n * GK;
-        sB[k * GN + n + (k >= GK / 2 ? 32 : 0)] = W2[i];
+    // W2 is [n][k]: a thread reads four consecutive k of one n (16 bytes) and stores them to four rows of B; lanes run
+    // over n, so the stores of a wave fall on consecutive banks (a scalar transposing copy put all 64 lanes on one bank)
+    for (int i = tid; i < GK * GN / 4; i += 256) {
+        const int n = i & (GN - 1), k4 = (i >> 7) * 4;
+        const float4 w = *(const float4*)(W2 + (size_t)n * GK + k4);
+        float* dst = sB + k4 * GN + n + (k4 >= GK / 2 ? 32 : 0);
+        dst[0] = w.x;
+        dst[GN] = w.y;
+        dst[2 * GN] = w.z;
+        dst[3 * GN] = w.w;
     }
     if (tid < GK) {
         sC1[0 * GK + tid] = W1[tid * 3];
@@ -428,14 +435,17 @@ __global__ __launch_bounds__(256, 2) void dense_dgrad_x3_kernel(const float* __r
     char* sBl = dg_smem + DG_PLANE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
-        const int k = idx >> 7, n = idx & 127;
-        const float v = G[idx];
-        const __bf16 hi = (__bf16)v;
-        const __bf16 lo = (__bf16)(v - (float)hi);
-        const int off = ((((n >> 5) * 8 + (k >> 4)) * 64 + (n & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7)) * 2;
-        *(__bf16*)(sBh + off) = hi;
-        *(__bf16*)(sBl + off) = lo;
+    // a thread makes whole fragments: the 8 consecutive rows k = 8 kg .. 8 kg + 7 of column n (reads coalesced over n)
+    for (int item = tid; item < 128 * 16; item += 256) {
+        const int n = item & 127, kg = item >> 7;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = G[(size_t)(8 * kg + j) * 128 + n];
+        dg_bf16x8 hi, lo;
+        dg_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+        const int off = (((n >> 5) * 8 + (kg >> 1)) * 64 + (n & 31) + 32 * (kg & 1)) * 16;
+        *(dg_bf16x8*)(sBh + off) = hi;
+        *(dg_bf16x8*)(sBl + off) = lo;
     }
     __syncthreads();
     float bv[4];
