@@ -15,6 +15,7 @@
 // dh1 needs no pass of its own.  Structure as tall_gemm_kernel<128,64>: persistent workgroups, W2 resident in LDS, the
 // next half tile (128 rows x 64 columns of dh2 and y2) in flight during the MFMAs.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 #include "train_act.h"
@@ -32,8 +33,37 @@ __device__ __forceinline__ int w2_row_offset(int k) { return k * FN + 32 * (k >>
 constexpr int F_CONST = 7;      // per column of layer 2: mean, rstd, gamma, beta, m1, m2, gamma * rstd
 constexpr int F_CONST1 = 8;     // per column of layer 1: three weights, bias, mean, rstd, gamma, beta
 constexpr size_t F_LDS_BYTES = ((size_t)F_W2_FLOATS + F_CONST * FK + F_CONST1 * FN) * sizeof(float);
+constexpr int F_X3_PLANE_BYTES = (FN / 32) * 8 * 64 * 16;      // W2 as B fragments of v_mfma_f32_32x32x16_bf16, one piece
+static_assert(2 * F_X3_PLANE_BYTES <= F_W2_FLOATS * 4, "the two bfloat16 planes of W2 fit the float32 image's LDS");
+
+typedef __attribute__((ext_vector_type(8))) __bf16 dg_bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 dg_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float dg_f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int dg_u32x4;
+constexpr int DG_PLANE_BYTES = 4 * 8 * 64 * 16;       // [column tile 4][step 8][lane 64] x 16 B
+constexpr size_t DG_LDS_BYTES = 2 * DG_PLANE_BYTES;
+
+// hi and lo pieces of eight floats as A/B fragment registers
+__device__ __forceinline__ void dg_split8(const float4& v0, const float4& v1, dg_bf16x8& hi, dg_bf16x8& lo) {
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    dg_u32x4 h, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(dg_f32x2{x[2 * q], x[2 * q + 1]}, dg_bf16x2));
+        const float r0 = x[2 * q] - __builtin_bit_cast(float, hp << 16);
+        const float r1 = x[2 * q + 1] - __builtin_bit_cast(float, hp & 0xffff0000u);
+        h[q] = hp;
+        l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(dg_f32x2{r0, r1}, dg_bf16x2));
+    }
+    hi = __builtin_bit_cast(dg_bf16x8, h);
+    lo = __builtin_bit_cast(dg_bf16x8, l);
+}
 }  // namespace
 
+// SPLIT: the product dy2 W2 as three products of bfloat16 pieces (dg_split8; a gradient term, as in dense_dgrad_x3_kernel
+// below) instead of v_mfma_f32_32x32x2_f32.  A lane then owns, per 16-term step ks of a phase, the 8 consecutive floats
+// [64p + 16ks + 8h, + 8) of its row; without SPLIT the 32 consecutive floats [64p + 32h, + 32).
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv2_bwd_fused_kernel(
     float* __restrict__ dh2, const float* __restrict__ y2, const float* __restrict__ mean2,
     const float* __restrict__ rstd2, const float* __restrict__ gamma2, const float* __restrict__ beta2,
@@ -48,7 +78,27 @@ __global__ __launch_bounds__(256, 2) void conv2_bwd_fused_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    for (int i = tid * 4; i < FK * FN; i += 1024) *(float4*)(sB + w2_row_offset(i / FN) + (i % FN)) = *(const float4*)(W2 + i);
+    // float4 q of a lane's phase sits at this column of the row
+    auto col_of = [&](int p, int q) { return SPLIT ? 64 * p + 16 * (q >> 1) + 8 * h + 4 * (q & 1) : 64 * p + 32 * h + 4 * q; };
+    char* sBh = (char*)f_smem;
+    char* sBl = sBh + F_X3_PLANE_BYTES;
+    if (SPLIT) {
+        // a thread makes whole fragments: rows k = 8 kg .. 8 kg + 7 of column n, both pieces
+        for (int item = tid; item < FN * (FK / 8); item += 256) {
+            const int n = item & (FN - 1), kg = item / FN;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = W2[(size_t)(8 * kg + j) * FN + n];
+            dg_bf16x8 hi, lo;
+            dg_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+            const int off = (((n >> 5) * 8 + (kg >> 1)) * 64 + (n & 31) + 32 * (kg & 1)) * 16;
+            *(dg_bf16x8*)(sBh + off) = hi;
+            *(dg_bf16x8*)(sBl + off) = lo;
+        }
+    } else {
+        for (int i = tid * 4; i < FK * FN; i += 1024)
+            *(float4*)(sB + w2_row_offset(i / FN) + (i % FN)) = *(const float4*)(W2 + i);
+    }
     if (tid < FK) {
         const float mu = mean2[tid], rs = rstd2[tid], ga = gamma2[tid];
         sC[0 * FK + tid] = mu;
@@ -86,12 +136,12 @@ __global__ __launch_bounds__(256, 2) void conv2_bwd_fused_kernel(
     auto load_phase = [&](int tile, int p) {
         int row = tile * 128 + wave * 32 + r;
         row = row < M ? row : M - 1;
-        const float4* sd = (const float4*)(dh2 + (size_t)row * FK + 64 * p + 32 * h);
-        const float4* sy = (const float4*)(y2 + (size_t)row * FK + 64 * p + 32 * h);
+        const float* sd = dh2 + (size_t)row * FK;
+        const float* sy = y2 + (size_t)row * FK;
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
-            a[q] = sd[q];
-            yv[q] = sy[q];
+            a[q] = *(const float4*)(sd + col_of(p, q));
+            yv[q] = *(const float4*)(sy + col_of(p, q));
         }
         if (p == 0) {
             xr[0] = X3[(size_t)row * 3];
@@ -114,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv2_bwd_fused_kernel(
             float4 d[PQ];
 #pragma unroll
             for (int q = 0; q < PQ; ++q) {
-                const float* cst = sC + 64 * p + 32 * h + 4 * q;
+                const float* cst = sC + col_of(p, q);
                 const float4 mu = *(const float4*)(cst), rs = *(const float4*)(cst + FK), ga = *(const float4*)(cst + 2 * FK),
                              be = *(const float4*)(cst + 3 * FK), a1 = *(const float4*)(cst + 4 * FK),
                              a2 = *(const float4*)(cst + 5 * FK), gr = *(const float4*)(cst + 6 * FK);
@@ -130,25 +180,43 @@ __global__ __launch_bounds__(256, 2) void conv2_bwd_fused_kernel(
                 d[q].w = gr.w * (g.w - a1.w - (y.w - mu.w) * rs.w * a2.w);
             }
             if (rowA < M) {
-                float4* dst = (float4*)(dh2 + (size_t)rowA * FK + 64 * p + 32 * h);
+                float* dst = dh2 + (size_t)rowA * FK;
 #pragma unroll
-                for (int q = 0; q < PQ; ++q) dst[q] = d[q];
+                for (int q = 0; q < PQ; ++q) *(float4*)(dst + col_of(p, q)) = d[q];
             }
             if (p == 0)
                 load_phase(tile, 1);
             else if (next < tiles)
                 load_phase(next, 0);
+            if (SPLIT) {
 #pragma unroll
-            for (int q = 0; q < PQ; ++q) {
-                const float av[4] = {d[q].x, d[q].y, d[q].z, d[q].w};
+                for (int ks = 0; ks < 4; ++ks) {
+                    dg_bf16x8 ah, al;
+                    dg_split8(d[2 * ks], d[2 * ks + 1], ah, al);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float* brow = sB + w2_row_offset(64 * p + 32 * h + 4 * q + e) + r;
-#pragma unroll
-                    for (int t = 0; t < FNT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], brow[32 * t], acc[t], 0, 0, 0);
+                    for (int t = 0; t < FNT; ++t) {
+                        const int off = ((t * 8 + 4 * p + ks) * 64 + lane) * 16;
+                        const dg_bf16x8 bh = *(const dg_bf16x8*)(sBh + off);
+                        const dg_bf16x8 bl = *(const dg_bf16x8*)(sBl + off);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < PQ; ++q) {
+                    const float av[4] = {d[q].x, d[q].y, d[q].z, d[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float* brow = sB + w2_row_offset(64 * p + 32 * h + 4 * q + e) + r;
+#pragma unroll
+                        for (int t = 0; t < FNT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], brow[32 * t], acc[t], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         // accumulator i of a lane: row (i&3) + 8(i>>2) + 4h of the wave's 32 rows, column 32t + r
@@ -402,31 +470,6 @@ hipError_t launch_conv12_fwd(const float* X3, const float* W1, const float* b1, 
 // workgroups, G resident in LDS as B fragments of v_mfma_f32_32x32x16_bf16 (two planes), a tile of 128 rows in two
 // phases of 64 summed terms, the next phase's floats in flight during the MFMAs.  Lane (r, h) owns row r of its wave's
 // 32 and, per 16-term step, the 8 consecutive floats [16 ks + 8 h, + 8).
-namespace {
-typedef __attribute__((ext_vector_type(8))) __bf16 dg_bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 dg_bf16x2;
-typedef __attribute__((ext_vector_type(2))) float dg_f32x2;
-typedef __attribute__((ext_vector_type(4))) unsigned int dg_u32x4;
-constexpr int DG_PLANE_BYTES = 4 * 8 * 64 * 16;       // [column tile 4][step 8][lane 64] x 16 B
-constexpr size_t DG_LDS_BYTES = 2 * DG_PLANE_BYTES;
-
-// hi and lo pieces of eight floats as A/B fragment registers
-__device__ __forceinline__ void dg_split8(const float4& v0, const float4& v1, dg_bf16x8& hi, dg_bf16x8& lo) {
-    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    dg_u32x4 h, l;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(dg_f32x2{x[2 * q], x[2 * q + 1]}, dg_bf16x2));
-        const float r0 = x[2 * q] - __builtin_bit_cast(float, hp << 16);
-        const float r1 = x[2 * q + 1] - __builtin_bit_cast(float, hp & 0xffff0000u);
-        h[q] = hp;
-        l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(dg_f32x2{r0, r1}, dg_bf16x2));
-    }
-    hi = __builtin_bit_cast(dg_bf16x8, h);
-    lo = __builtin_bit_cast(dg_bf16x8, l);
-}
-}  // namespace
-
 __global__ __launch_bounds__(256, 2) void dense_dgrad_x3_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                                 const float* __restrict__ ub, float* __restrict__ Y,
                                                                 int M) {
@@ -522,11 +565,13 @@ hipError_t launch_conv2_bwd_fused(float* dh2, const float* y2, const float* mean
                                   const float* mean1, const float* rstd1, const float* gamma1, const float* beta1,
                                   double* part, hipStream_t s) {
     if (!dh2 || !y2 || !W2 || !dh1 || !X3 || !part || M < 1) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute((const void*)conv2_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)F_LDS_BYTES);
+    // PNGPD_TRAIN_DGRAD=f32 keeps the product on the float32 matrix instruction (as for dense_dgrad_x3_kernel)
+    const char* env = getenv("PNGPD_TRAIN_DGRAD");
+    auto kern = env && env[0] == 'f' ? conv2_bwd_fused_kernel<false> : conv2_bwd_fused_kernel<true>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(conv2_bwd_fused_kernel, dim3(tall_gemm_blocks(M)), dim3(256), F_LDS_BYTES, s, dh2, y2, mean2, rstd2,
-                       gamma2, beta2, m1, m2, W2, dh1, M, X3, W1, b1, mean1, rstd1, gamma1, beta1, part);
+    hipLaunchKernelGGL(kern, dim3(tall_gemm_blocks(M)), dim3(256), F_LDS_BYTES, s, dh2, y2, mean2, rstd2, gamma2, beta2, m1,
+                       m2, W2, dh1, M, X3, W1, b1, mean1, rstd1, gamma1, beta1, part);
     return hipGetLastError();
 }
 
